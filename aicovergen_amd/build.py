@@ -1,0 +1,66 @@
+"""Build libaicg_hip.so (gfx950) in-tree with hipcc.  Used by __graft_entry__.build()."""
+import concurrent.futures
+import glob
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libaicg_hip.so")
+OBJ_DIR = os.path.join(HERE, "build")
+
+
+def _hipcc():
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: cannot build libaicg_hip.so")
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
+def build_hip(force=False, verbose=True):
+    """Compile every csrc/*.hip for gfx950 and link libaicg_hip.so next to this file."""
+    hipcc = _hipcc()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+    jobs = []
+    objs = []
+    for src in sources():
+        obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+        objs.append(obj)
+        if force or not _newer(obj, [src] + hdrs):
+            jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return cmd, r.returncode, r.stdout + r.stderr
+
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as ex:
+        for cmd, rc, log in ex.map(run, jobs):
+            if verbose and log.strip():
+                print(log, file=sys.stderr)
+            if rc != 0:
+                raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), log))
+    if jobs or force or not os.path.exists(OUT):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed: %s\n%s" % (" ".join(cmd), r.stdout + r.stderr))
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build_hip(force="--force" in sys.argv))

@@ -1,0 +1,52 @@
+// Shared helpers for the gfx950 kernels of libaicg_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/aicg.h"
+
+namespace aicg {
+
+// error plumbing: the C ABI returns negative codes and keeps a per-thread message for aicg_last_error()
+void set_error(const char* fmt, ...);
+int fail(int code, const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(AICG_E_HIP, "%s: %s", what, hipGetErrorString(e));
+    return AICG_OK;
+}
+
+__host__ __device__ inline int idiv_up(int a, int b) { return (a + b - 1) / b; }
+__host__ __device__ inline long ldiv_up(long a, long b) { return (a + b - 1) / b; }
+__host__ __device__ inline int imin(int a, int b) { return a < b ? a : b; }
+__host__ __device__ inline int imax(int a, int b) { return a > b ? a : b; }
+__host__ __device__ inline long lmin(long a, long b) { return a < b ? a : b; }
+__host__ __device__ inline long lmax(long a, long b) { return a > b ? a : b; }
+
+// activations shared by conv epilogues and elementwise kernels (codes: include/aicg.h)
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+    switch (act) {
+        case AICG_ACT_NONE: return v;
+        case AICG_ACT_RELU: return v > 0.f ? v : 0.f;
+        case AICG_ACT_LRELU: return v > 0.f ? v : v * slope;
+        case AICG_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        case AICG_ACT_TANH: return tanhf(v);
+        case AICG_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        default: return v;
+    }
+}
+
+// block->XCD aware remap (guide T1, bijective form): consecutive logical ids share an XCD's L2.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
+    const unsigned nx = 8;
+    if (nwg < nx * 2) return bid;
+    const unsigned q = nwg / nx, r = nwg % nx;
+    const unsigned xcd = bid % nx, pos = bid / nx;
+    const unsigned base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + pos;
+}
+
+}  // namespace aicg
