@@ -1,0 +1,216 @@
+// Fused softmax attention on fp32 MFMA for channel-major (C, T) activations; T x T scores never reach HBM.
+//   * enc_p MultiHeadAttention with windowed relative-position keys/values (reference
+//     src/infer_pack/attentions.py:226-275; closed form: SURVEY appendix B.3) -- 2 heads x 96
+//   * HuBERT self-attention (fairseq MultiheadAttention, called at src/vc_infer_pipeline.py:398-406) -- 12 x 64
+//
+// One wave owns 32 queries.  S^T = K Q^T is computed "swapped" (A = K tile from LDS, B = Q from
+// registers) so that, in the 32x32 MFMA accumulator layout, a lane holds 16 keys of ONE query column:
+// the row max / row sum are lane-local plus one xor-32 shuffle, and the rescale factor of the running
+// output is a per-lane scalar.  O^T += V^T P^T then uses the S^T accumulator registers directly as the B
+// operand: MFMA step r pairs key j_r (lanes 0-31) with key j_r + 4 (lanes 32-63), which is exactly the
+// pair of rows register r holds in the two half-waves -- no cross-lane movement of P.
+#include "common.h"
+
+namespace aicg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct AttnArgs {
+    const float* q;
+    const float* k;
+    const float* v;
+    const float* relk;  // (H, 2w+1, T) precomputed q_i . E^k_m, or null
+    float* o;
+    float* lse;  // (H, T) log-sum-exp per query, or null
+    int T, H, window;
+    long ldq, ldk, ldv, ldo;  // row (channel) strides
+    float scale;
+};
+
+static constexpr int KT = 32;       // keys per tile
+static constexpr int KV_LD = 33;    // LDS row stride of K/V tiles (conflict-free column reads)
+
+template <int D>
+__global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs p) {
+    constexpr int DT = D / 32;
+    __shared__ float Ks[D * KV_LD];
+    __shared__ float Vs[D * KV_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int h = blockIdx.y;
+    const int i0 = blockIdx.x * 128 + wave * 32;  // first query of this wave
+    const int qi = i0 + l31;
+    const float* qh = p.q + (long)h * D * p.ldq;
+    const float* kh = p.k + (long)h * D * p.ldk;
+    const float* vh = p.v + (long)h * D * p.ldv;
+
+    // Q^T fragments: qreg[s] = q[2s + half][qi]
+    float qreg[D / 2];
+#pragma unroll
+    for (int s = 0; s < D / 2; ++s) qreg[s] = (qi < p.T) ? qh[(long)(2 * s + half) * p.ldq + qi] * p.scale : 0.f;
+
+    f32x16 acc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles = idiv_up(p.T, KT);
+    const int blk_q0 = blockIdx.x * 128;
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int j0 = kt * KT;
+        __syncthreads();
+        for (int idx = tid; idx < D * KT; idx += 256) {
+            const int d = idx >> 5, j = idx & 31;
+            const bool ok = (j0 + j) < p.T;
+            Ks[d * KV_LD + j] = ok ? kh[(long)d * p.ldk + j0 + j] : 0.f;
+            Vs[d * KV_LD + j] = ok ? vh[(long)d * p.ldv + j0 + j] : 0.f;
+        }
+        __syncthreads();
+        // S^T tile: rows = keys, cols = queries
+        f32x16 st;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < D / 2; ++s) {
+            const float a = Ks[(2 * s + half) * KV_LD + l31];
+            st = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qreg[s], st, 0, 0, 0);
+        }
+        // relative-position key bias on the band |j - i| <= window (only near-diagonal tiles)
+        if (p.relk && j0 + KT - 1 >= blk_q0 - p.window && j0 <= blk_q0 + 127 + p.window) {
+            const float* rk = p.relk + (long)h * (2 * p.window + 1) * p.T;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int dlt = j - qi;
+                if (qi < p.T && j < p.T && dlt >= -p.window && dlt <= p.window)
+                    st[r] += rk[(long)(dlt + p.window) * p.T + qi];
+            }
+        }
+        // online softmax over this tile's 32 keys of query qi
+        float m_t = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (j >= p.T) st[r] = -INFINITY;
+            m_t = fmaxf(m_t, st[r]);
+        }
+        m_t = fmaxf(m_t, __shfl_xor(m_t, 32));
+        const float m_new = fmaxf(m_run, m_t);
+        const float alpha = expf(m_run - m_new);
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            st[r] = expf(st[r] - m_new);
+            rs += st[r];
+        }
+        rs += __shfl_xor(rs, 32);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[dt][r] *= alpha;
+        // O^T += V^T P^T : step r contracts keys (j_r, j_r + 4)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jr = (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const float a = Vs[(dt * 32 + l31) * KV_LD + jr];
+                acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, st[r], acc[dt], 0, 0, 0);
+            }
+        }
+    }
+    if (qi < p.T) {
+        const float inv = 1.f / l_run;
+        float* oh = p.o + (long)h * D * p.ldo;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                oh[(long)d * p.ldo + qi] = acc[dt][r] * inv;
+            }
+        if (p.lse && half == 0) p.lse[(long)h * p.T + qi] = m_run + logf(l_run);
+    }
+}
+
+// Relative-position VALUE term: o_i += sum_{|j-i|<=w} P_ij E^v_{j-i+w}, with P rebuilt from the saved
+// log-sum-exp (attentions.py:264-271).  One thread per (query, head); 2w+1 scores in registers.
+template <int D, int NW>
+__global__ void __launch_bounds__(64) attn_relv_kernel(AttnArgs p, const float* __restrict__ relv_emb) {
+    __shared__ float Ev[NW * D];
+    for (int idx = threadIdx.x; idx < NW * D; idx += 64) Ev[idx] = relv_emb[idx];
+    __syncthreads();
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int h = blockIdx.y;
+    if (i >= p.T) return;
+    const int w = p.window;
+    const float* qh = p.q + (long)h * D * p.ldq;
+    const float* kh = p.k + (long)h * D * p.ldk;
+    float s[NW];
+#pragma unroll
+    for (int m = 0; m < NW; ++m) s[m] = 0.f;
+    for (int d = 0; d < D; ++d) {
+        const float qd = qh[(long)d * p.ldq + i] * p.scale;
+        const float* kr = kh + (long)d * p.ldk;
+#pragma unroll
+        for (int m = 0; m < NW; ++m) {
+            const int j = i + m - w;
+            if (j >= 0 && j < p.T) s[m] += qd * kr[j];
+        }
+    }
+    const float lse = p.lse[(long)h * p.T + i];
+    const float* rk = p.relk + (long)h * NW * p.T;
+#pragma unroll
+    for (int m = 0; m < NW; ++m) {
+        const int j = i + m - w;
+        s[m] = (j >= 0 && j < p.T) ? expf(s[m] + rk[(long)m * p.T + i] - lse) : 0.f;
+    }
+    float* oh = p.o + (long)h * D * p.ldo;
+    for (int d = 0; d < D; ++d) {
+        float a = 0.f;
+#pragma unroll
+        for (int m = 0; m < NW; ++m) a += s[m] * Ev[m * D + d];
+        oh[(long)d * p.ldo + i] += a;
+    }
+}
+
+}  // namespace aicg
+
+using namespace aicg;
+
+extern "C" int aicg_attention(const float* q, const float* k, const float* v, const float* relk, float* o, float* lse, int T,
+                              int H, int D, int window, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale,
+                              void* stream) {
+    if (!q || !k || !v || !o) return fail(AICG_E_ARG, "aicg_attention: null pointer");
+    if (T < 1 || H < 1) return fail(AICG_E_SHAPE, "aicg_attention: bad shape");
+    AttnArgs p{q, k, v, relk, o, lse, T, H, window, (long)ldq, (long)ldk, (long)ldv, (long)ldo, scale};
+    dim3 grid((unsigned)idiv_up(T, 128), (unsigned)H);
+    if (D == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_fwd_kernel<64>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else if (D == 96) hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_fwd_kernel<96>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else if (D == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_fwd_kernel<32>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else if (D == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_fwd_kernel<128>), grid, dim3(256), 0, (hipStream_t)stream, p);
+    else return fail(AICG_E_SHAPE, "aicg_attention: head dim %d not in {32,64,96,128}", D);
+    return check_launch("attn_fwd_kernel");
+}
+
+extern "C" int aicg_attention_relv(const float* q, const float* k, const float* relk, const float* relv_emb,
+                                   const float* lse, float* o, int T, int H, int D, int window, int64_t ldq, int64_t ldk,
+                                   int64_t ldo, float scale, void* stream) {
+    if (!q || !k || !relk || !relv_emb || !lse || !o) return fail(AICG_E_ARG, "aicg_attention_relv: null pointer");
+    AttnArgs p{q, k, nullptr, relk, o, const_cast<float*>(lse), T, H, window, (long)ldq, (long)ldk, 0, (long)ldo, scale};
+    dim3 grid((unsigned)idiv_up(T, 64), (unsigned)H);
+    if (D == 96 && window == 10)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_relv_kernel<96, 21>), grid, dim3(64), 0, (hipStream_t)stream, p, relv_emb);
+    else if (D == 64 && window == 10)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_relv_kernel<64, 21>), grid, dim3(64), 0, (hipStream_t)stream, p, relv_emb);
+    else if (D == 32 && window == 10)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_relv_kernel<32, 21>), grid, dim3(64), 0, (hipStream_t)stream, p, relv_emb);
+    else if (D == 32 && window == 4)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_relv_kernel<32, 9>), grid, dim3(64), 0, (hipStream_t)stream, p, relv_emb);
+    else return fail(AICG_E_SHAPE, "aicg_attention_relv: (D=%d, window=%d) not instantiated", D, window);
+    return check_launch("attn_relv_kernel");
+}

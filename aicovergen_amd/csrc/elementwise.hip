@@ -1,0 +1,224 @@
+// HBM-bound helper kernels of the RVC synthesizer: col2im for transposed convolutions, the NSF sine
+// source, the WaveNet gate, the prior sample, nearest x2 + protect blend.  One pass over the data each,
+// unit-stride along time so every wave issues full 256-byte rows.
+#include "common.h"
+
+namespace aicg {
+
+// ---- col2im: gather form of ConvTranspose (reference models.py:453-463 ups; rmvpe.py:147-155) ---------
+// cols: (N, Cout*KH*KW, Hi, Wi) = the 1x1 GEMM  W[ci][co,kh,kw]^T x ;  out[n,co,ho,wo] =
+//   act(bias[co] + sum over (kh,kw) with (ho+ph-kh) % sh == 0, (wo+pw-kw) % sw == 0 of cols[n,(co,kh,kw),hi,wi]) + add
+struct Col2imArgs {
+    const float* cols;
+    const float* bias;
+    const float* add;
+    float* out;
+    int N, Cout, Hi, Wi, Ho, Wo, KH, KW, sh, sw, ph, pw, act;
+    float slope;
+    long o_sn, o_sc, o_sh, a_sn, a_sc, a_sh;
+};
+
+__global__ void __launch_bounds__(256) col2im_kernel(Col2imArgs p) {
+    const long total = (long)p.N * p.Cout * p.Ho * p.Wo;
+    const long plane = (long)p.Hi * p.Wi;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int wo = (int)(i % p.Wo);
+        long t = i / p.Wo;
+        const int ho = (int)(t % p.Ho);
+        t /= p.Ho;
+        const int co = (int)(t % p.Cout);
+        const int n = (int)(t / p.Cout);
+        float acc = p.bias ? p.bias[co] : 0.f;
+        const float* cn = p.cols + (long)n * p.Cout * p.KH * p.KW * plane;
+        for (int kh = (ho + p.ph) % p.sh; kh < p.KH; kh += p.sh) {
+            const int hi = (ho + p.ph - kh) / p.sh;
+            if (ho + p.ph - kh < 0) break;
+            if (hi >= p.Hi) continue;
+            for (int kw = (wo + p.pw) % p.sw; kw < p.KW; kw += p.sw) {
+                const int wi = (wo + p.pw - kw) / p.sw;
+                if (wo + p.pw - kw < 0) break;
+                if (wi >= p.Wi) continue;
+                acc += cn[((long)(co * p.KH + kh) * p.KW + kw) * plane + (long)hi * p.Wi + wi];
+            }
+        }
+        acc = apply_act(acc, p.act, p.slope);
+        if (p.add) acc += p.add[(long)n * p.a_sn + (long)co * p.a_sc + (long)ho * p.a_sh + wo];
+        p.out[(long)n * p.o_sn + (long)co * p.o_sc + (long)ho * p.o_sh + wo] = acc;
+    }
+}
+
+// ---- NSF sine source (reference models.py:320-370 SineGen.forward + :414-419 SourceModuleHnNSF) --------
+// harmonic_num = 0.  phase[n] = sum_{m<=n} rad[floor(m/upp)], rad = (f0/sr) mod 1; the reference's
+// cumsum_shift only removes integers from the running fp32 sum, so the phase is
+// carried modulo 1 in fp64: frame prefix (one thread block scan) + (i+1)*rad inside the frame.
+__global__ void __launch_bounds__(256) sine_frame_prefix_kernel(const float* __restrict__ f0, double* __restrict__ prefix,
+                                                                int T, int upp, float sr) {
+    // single workgroup: blocked scan over frames; prefix[t] = frac(sum_{u<t} rad_u * upp)
+    __shared__ double part[256];
+    const int tid = threadIdx.x;
+    const int per = (T + 255) / 256;
+    const int t0 = tid * per, t1 = imin(T, t0 + per);
+    double s = 0.0;
+    for (int t = t0; t < t1; ++t) {
+        const float rad = fmodf(f0[t] / sr, 1.0f);
+        s += (double)rad * (double)upp;
+        s -= floor(s);
+    }
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) {
+        double run = 0.0;
+        for (int i = 0; i < 256; ++i) {
+            const double v = part[i];
+            part[i] = run;
+            run += v;
+            run -= floor(run);
+        }
+    }
+    __syncthreads();
+    double run = part[tid];
+    for (int t = t0; t < t1; ++t) {
+        prefix[t] = run;
+        const float rad = fmodf(f0[t] / sr, 1.0f);
+        run += (double)rad * (double)upp;
+        run -= floor(run);
+    }
+}
+
+__global__ void __launch_bounds__(256) sine_source_kernel(const float* __restrict__ f0, const double* __restrict__ prefix,
+                                                          const float* __restrict__ noise, float* __restrict__ out,
+                                                          int T, int upp, float sr, float sine_amp, float noise_std,
+                                                          float lin_w, float lin_b) {
+    const long total = (long)T * upp;
+    for (long n = (long)blockIdx.x * blockDim.x + threadIdx.x; n < total; n += (long)gridDim.x * blockDim.x) {
+        const int t = (int)(n / upp);
+        const int i = (int)(n - (long)t * upp);
+        const float f = f0[t];
+        const float rad = fmodf(f / sr, 1.0f);
+        double ph = prefix[t] + (double)(i + 1) * (double)rad;
+        ph -= floor(ph);
+        const float sine = sinf((float)(ph * 6.283185307179586476925)) * sine_amp;
+        const float uv = f > 0.f ? 1.f : 0.f;
+        const float namp = uv * noise_std + (1.f - uv) * sine_amp / 3.f;
+        const float v = sine * uv + namp * noise[n];
+        out[n] = tanhf(lin_w * v + lin_b);  // l_linear (1->1) + tanh (models.py:418)
+    }
+}
+
+// ---- WaveNet gate: out[c] = tanh(a[c]) * sigmoid(a[c + C])  (commons.py:105-112; bias/cond already added) -----
+__global__ void __launch_bounds__(256) gate_kernel(const float* __restrict__ a, float* __restrict__ out, int N, int C,
+                                                   long T) {
+    const long total = (long)N * C * T;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long t = i % T;
+        const long nc = i / T;
+        const int c = (int)(nc % C);
+        const long n = nc / C;
+        const float ta = a[(n * 2 * C + c) * T + t];
+        const float sa = a[(n * 2 * C + C + c) * T + t];
+        out[i] = tanhf(ta) * (1.f / (1.f + expf(-sa)));
+    }
+}
+
+// ---- prior sample: z_p = m + exp(logs) * noise * scale  (models.py:748); stats = [m ; logs] -----------------
+__global__ void __launch_bounds__(256) prior_sample_kernel(const float* __restrict__ stats, const float* __restrict__ noise,
+                                                           float* __restrict__ out, int C, long T, float scale) {
+    const long total = (long)C * T;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const float m = stats[i], logs = stats[total + i];
+        out[i] = m + expf(logs) * noise[i] * scale;
+    }
+}
+
+// ---- nearest x2 upsample + protect blend + transpose to channel-major  (vc_infer_pipeline.py:433-452) --------
+// feats: (Th, C) token-major HuBERT output.  out[c][t] = f*pf + f*(1-pf) semantics of the reference:
+//   feats = feats * pitchff + feats0 * (1 - pitchff), where feats0 is the pre-index copy (== feats when no
+//   faiss index is used) and pitchff = 1 if pitchf > 0 else protect.   feats0 may be null (no protect).
+__global__ void __launch_bounds__(256) feats_prepare_kernel(const float* __restrict__ feats, const float* __restrict__ feats0,
+                                                            const float* __restrict__ pitchf, float* __restrict__ out,
+                                                            int Th, int C, int T, float protect) {
+    // tile transpose through LDS: reads unit-stride along C, writes unit-stride along T
+    __shared__ float tile[32][33];
+    const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int t = t0 + r, c = c0 + tx;
+        float v = 0.f;
+        if (t < T && c < C) {
+            const int th = imin(t >> 1, Th - 1);
+            v = feats[(long)th * C + c];
+            if (feats0) {
+                const float f = pitchf[t];
+                float pf = f;
+                if (f > 0.f) pf = 1.f;      // pitchff[pitchf > 0] = 1
+                if (f < 1.f) pf = protect;  // pitchff[pitchf < 1] = protect  (both tests on the original pitchf)
+                v = v * pf + feats0[(long)th * C + c] * (1.f - pf);
+            }
+        }
+        tile[r][tx] = v;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, t = t0 + tx;
+        if (c < C && t < T) out[(long)c * T + t] = tile[tx][r];
+    }
+}
+
+static unsigned ew_grid(long total) { return (unsigned)lmax(1, lmin((total + 255) / 256, 256L * 16)); }
+
+}  // namespace aicg
+
+using namespace aicg;
+
+extern "C" int aicg_col2im(const float* cols, const float* bias, const float* add, float* out, int N, int Cout, int Hi,
+                           int Wi, int Ho, int Wo, int KH, int KW, int stride_h, int stride_w, int pad_h, int pad_w,
+                           int act, float slope, int64_t o_sn, int64_t o_sc, int64_t o_sh, int64_t a_sn, int64_t a_sc,
+                           int64_t a_sh, void* stream) {
+    if (!cols || !out) return fail(AICG_E_ARG, "aicg_col2im: null pointer");
+    if (KH < 1 || KW < 1 || stride_h < 1 || stride_w < 1) return fail(AICG_E_SHAPE, "aicg_col2im: bad geometry");
+    const long total = (long)N * Cout * Ho * Wo;
+    if (total == 0) return AICG_OK;
+    Col2imArgs p{cols, bias, add, out, N, Cout, Hi, Wi, Ho, Wo, KH, KW, stride_h, stride_w, pad_h, pad_w, act, slope,
+                 (long)o_sn, (long)o_sc, (long)o_sh, (long)a_sn, (long)a_sc, (long)a_sh};
+    hipLaunchKernelGGL(col2im_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, p);
+    return check_launch("col2im_kernel");
+}
+
+extern "C" int aicg_sine_source(const float* f0, const float* noise, double* prefix_scratch, float* out, int T, int upp,
+                                float sr, float sine_amp, float noise_std, float lin_w, float lin_b, void* stream) {
+    if (!f0 || !noise || !prefix_scratch || !out) return fail(AICG_E_ARG, "aicg_sine_source: null pointer");
+    if (T < 0 || upp < 1) return fail(AICG_E_SHAPE, "aicg_sine_source: bad shape");
+    if (T == 0) return AICG_OK;
+    hipLaunchKernelGGL(sine_frame_prefix_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, f0, prefix_scratch, T, upp, sr);
+    hipLaunchKernelGGL(sine_source_kernel, dim3(ew_grid((long)T * upp)), dim3(256), 0, (hipStream_t)stream, f0,
+                       (const double*)prefix_scratch, noise, out, T, upp, sr, sine_amp, noise_std, lin_w, lin_b);
+    return check_launch("sine_source_kernel");
+}
+
+extern "C" int aicg_gate_tanh_sigmoid(const float* a, float* out, int N, int C, int64_t T, void* stream) {
+    if (!a || !out) return fail(AICG_E_ARG, "aicg_gate_tanh_sigmoid: null pointer");
+    const long total = (long)N * C * T;
+    if (total == 0) return AICG_OK;
+    hipLaunchKernelGGL(gate_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, a, out, N, C, (long)T);
+    return check_launch("gate_kernel");
+}
+
+extern "C" int aicg_prior_sample(const float* stats, const float* noise, float* out, int C, int64_t T, float scale,
+                                 void* stream) {
+    if (!stats || !noise || !out) return fail(AICG_E_ARG, "aicg_prior_sample: null pointer");
+    if ((long)C * T == 0) return AICG_OK;
+    hipLaunchKernelGGL(prior_sample_kernel, dim3(ew_grid((long)C * T)), dim3(256), 0, (hipStream_t)stream, stats, noise,
+                       out, C, (long)T, scale);
+    return check_launch("prior_sample_kernel");
+}
+
+extern "C" int aicg_feats_prepare(const float* feats, const float* feats0, const float* pitchf, float* out, int Th, int C,
+                                  int T, float protect, void* stream) {
+    if (!feats || !out || (feats0 && !pitchf)) return fail(AICG_E_ARG, "aicg_feats_prepare: null pointer");
+    if (T > 2 * Th) return fail(AICG_E_SHAPE, "aicg_feats_prepare: T=%d exceeds 2*Th=%d", T, 2 * Th);
+    if (T == 0 || C == 0) return AICG_OK;
+    dim3 grid((unsigned)idiv_up(T, 32), (unsigned)idiv_up(C, 32));
+    hipLaunchKernelGGL(feats_prepare_kernel, grid, dim3(256), 0, (hipStream_t)stream, feats, feats0, pitchf, out, Th, C, T,
+                       protect);
+    return check_launch("feats_prepare_kernel");
+}

@@ -100,3 +100,271 @@ def istft(spec, n_fft, hop, length, frame_major=False, window=None):
               n_fft, n_frames, nb, 2 * nb * n_frames, nb * n_frames, i_bin, i_frame, st)
     _lib.call("aicg_istft_ola", _ptr(frames), _ptr(window), _ptr(out), n_sig, length, n_fft, hop, n_frames, st)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# Convolution (implicit GEMM on fp32 MFMA)
+# ---------------------------------------------------------------------------------------------------
+import ctypes
+
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_GELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
+
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of aicg_conv_desc (include/aicg.h)."""
+    _fields_ = [(n, ctypes.c_int32) for n in
+                ("N", "Cin", "H", "W", "Cout", "Ho", "Wo", "KH", "KW", "stride_h", "stride_w", "pad_h", "pad_w",
+                 "dil_h", "dil_w", "groups")] + \
+               [(n, ctypes.c_int64) for n in ("x_sn", "x_sc", "x_sh", "y_sn", "y_sc", "y_sh", "r_sn", "r_sc", "r_sh")] + \
+               [("pre_act", ctypes.c_int32), ("pre_slope", ctypes.c_float), ("act", ctypes.c_int32),
+                ("act_slope", ctypes.c_float), ("out_scale", ctypes.c_float), ("accumulate", ctypes.c_int32),
+                ("res_before_act", ctypes.c_int32)]
+
+
+def conv_bkc(taps):
+    return _lib.get().aicg_conv_bkc(int(taps))
+
+
+def pack_conv_weight(w, groups=1):
+    """(Cout, Cin/groups, KH, KW) -> per group [chunk][tap][channel in chunk][Mpad] (pure re-layout + zero pad)."""
+    w = w.detach().to(torch.float32)
+    cout, cin_g, kh, kw = w.shape
+    taps = kh * kw
+    bkc = conv_bkc(taps)
+    cout_g = cout // groups
+    mpad = (cout_g + 31) // 32 * 32
+    nchunk = (cin_g + bkc - 1) // bkc
+    wg = w.reshape(groups, cout_g, cin_g, taps)
+    wp = torch.zeros((groups, cout_g, nchunk * bkc, taps), dtype=torch.float32, device=w.device)
+    wp[:, :, :cin_g] = wg
+    wp = wp.reshape(groups, cout_g, nchunk, bkc, taps).permute(0, 2, 4, 3, 1)  # g, chunk, tap, ci, co
+    out = torch.zeros((groups, nchunk, taps, bkc, mpad), dtype=torch.float32, device=w.device)
+    out[..., :cout_g] = wp
+    return out.contiguous()
+
+
+class PackedConv:
+    """A convolution layer ready for aicg_conv_forward: packed weights + geometry.  1-D layers use KH=1."""
+
+    def __init__(self, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, device=None):
+        if weight.dim() == 3:  # Conv1d (Cout, Cin_g, K)
+            weight = weight.unsqueeze(2)
+            stride, padding, dilation = (1, _one(stride)), (0, _one(padding)), (1, _one(dilation))
+        elif weight.dim() == 2:  # Linear (out, in)
+            weight = weight[:, :, None, None]
+            stride, padding, dilation = (1, 1), (0, 0), (1, 1)
+        else:
+            stride, padding, dilation = _pair(stride), _pair(padding), _pair(dilation)
+        self.cout, cin_g, self.kh, self.kw = weight.shape
+        self.cin = cin_g * groups
+        self.groups = groups
+        self.stride, self.padding, self.dilation = stride, padding, dilation
+        device = weight.device if device is None else device
+        self.w = pack_conv_weight(weight.to(device), groups)
+        self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
+
+    def out_hw(self, h, w):
+        ho = (h + 2 * self.padding[0] - self.dilation[0] * (self.kh - 1) - 1) // self.stride[0] + 1
+        wo = (w + 2 * self.padding[1] - self.dilation[1] * (self.kw - 1) - 1) // self.stride[1] + 1
+        return ho, wo
+
+
+def _one(v):
+    return int(v[0]) if isinstance(v, (tuple, list)) else int(v)
+
+
+def _pair(v):
+    return (int(v[0]), int(v[1])) if isinstance(v, (tuple, list)) else (int(v), int(v))
+
+
+def _as4d(t):
+    return t.unsqueeze(2) if t.dim() == 3 else t
+
+
+def conv(x, pc, res=None, out=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NONE, act_slope=0.0, out_scale=1.0,
+         accumulate=False, bias=None, res_before_act=False):
+    """y = [y +] out_scale * (act(conv(pre_act(x)) + bias) + res).  x: (N,C,T) or (N,C,H,W), last dim contiguous;
+    views with arbitrary batch/channel/row strides are accepted for x, res and out."""
+    is1d = x.dim() == 3
+    x4 = _as4d(x)
+    n, c, h, w = x4.shape
+    assert c == pc.cin, "conv: input has %d channels, layer expects %d" % (c, pc.cin)
+    assert x4.stride(3) == 1 or w == 1
+    ho, wo = pc.out_hw(h, w)
+    if out is None:
+        out = torch.empty((n, pc.cout, wo) if is1d else (n, pc.cout, ho, wo), dtype=torch.float32, device=x.device)
+        assert not accumulate
+    o4 = _as4d(out)
+    assert o4.shape == (n, pc.cout, ho, wo), (o4.shape, (n, pc.cout, ho, wo))
+    assert o4.stride(3) == 1 or wo == 1
+    r4 = None
+    if res is not None:
+        r4 = _as4d(res)
+        assert r4.shape == o4.shape and (r4.stride(3) == 1 or wo == 1)
+    b = pc.bias if bias is None else bias
+    _check(x, out, res, pc.w, b)
+    d = ConvDesc()
+    d.N, d.Cin, d.H, d.W, d.Cout, d.Ho, d.Wo = n, c, h, w, pc.cout, ho, wo
+    d.KH, d.KW = pc.kh, pc.kw
+    d.stride_h, d.stride_w = pc.stride
+    d.pad_h, d.pad_w = pc.padding
+    d.dil_h, d.dil_w = pc.dilation
+    d.groups = pc.groups
+    d.x_sn, d.x_sc, d.x_sh = x4.stride(0), x4.stride(1), x4.stride(2)
+    d.y_sn, d.y_sc, d.y_sh = o4.stride(0), o4.stride(1), o4.stride(2)
+    if r4 is not None:
+        d.r_sn, d.r_sc, d.r_sh = r4.stride(0), r4.stride(1), r4.stride(2)
+    d.pre_act, d.pre_slope, d.act, d.act_slope = pre_act, pre_slope, act, act_slope
+    d.out_scale, d.accumulate = out_scale, 1 if accumulate else 0
+    d.res_before_act = 1 if res_before_act else 0
+    _lib.call("aicg_conv_forward", ctypes.addressof(d), _ptr(x4), _ptr(pc.w), _ptr(b), _ptr(r4), _ptr(o4), _stream(x))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# Transposed convolution = 1x1 GEMM (aicg_conv_forward) + gather (aicg_col2im)
+# ---------------------------------------------------------------------------------------------------
+class PackedConvTranspose:
+    """ConvTranspose1d/2d weights (Cin, Cout, K) / (Cin, Cout, KH, KW) re-laid-out as the (Cout*KH*KW, Cin)
+    matrix of the 1x1 GEMM; `bias` is applied by col2im."""
+
+    def __init__(self, weight, bias=None, stride=1, padding=0, output_padding=0, device=None):
+        if weight.dim() == 3:
+            weight = weight.unsqueeze(2)
+            stride, padding, output_padding = (1, _one(stride)), (0, _one(padding)), (0, _one(output_padding))
+        else:
+            stride, padding, output_padding = _pair(stride), _pair(padding), _pair(output_padding)
+        self.cin, self.cout, self.kh, self.kw = weight.shape
+        self.stride, self.padding, self.output_padding = stride, padding, output_padding
+        device = weight.device if device is None else device
+        gemm_w = weight.detach().permute(1, 2, 3, 0).reshape(self.cout * self.kh * self.kw, self.cin)
+        self.gemm = PackedConv(gemm_w.contiguous(), None, device=device)
+        self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
+
+    def out_hw(self, h, w):
+        ho = (h - 1) * self.stride[0] - 2 * self.padding[0] + self.kh + self.output_padding[0]
+        wo = (w - 1) * self.stride[1] - 2 * self.padding[1] + self.kw + self.output_padding[1]
+        return ho, wo
+
+
+def conv_transpose(x, pt, out=None, add=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NONE, act_slope=0.0):
+    """y = act(conv_transpose(pre_act(x)) + bias) + add."""
+    is1d = x.dim() == 3
+    x4 = _as4d(x)
+    n, c, h, w = x4.shape
+    cols = conv(x4, pt.gemm, pre_act=pre_act, pre_slope=pre_slope)  # (N, Cout*KH*KW, H, W)
+    ho, wo = pt.out_hw(h, w)
+    if out is None:
+        out = torch.empty((n, pt.cout, wo) if is1d else (n, pt.cout, ho, wo), dtype=torch.float32, device=x.device)
+    o4 = _as4d(out)
+    assert o4.shape == (n, pt.cout, ho, wo) and (o4.stride(3) == 1 or wo == 1)
+    a4 = None if add is None else _as4d(add)
+    if a4 is not None:
+        assert a4.shape == o4.shape and (a4.stride(3) == 1 or wo == 1)
+    _check(cols, out, add, pt.bias)
+    asn, asc, ash = (a4.stride(0), a4.stride(1), a4.stride(2)) if a4 is not None else (0, 0, 0)
+    _lib.call("aicg_col2im", _ptr(cols), _ptr(pt.bias), _ptr(a4), _ptr(o4), n, pt.cout, h, w, ho, wo, pt.kh, pt.kw,
+              pt.stride[0], pt.stride[1], pt.padding[0], pt.padding[1], act, act_slope,
+              o4.stride(0), o4.stride(1), o4.stride(2), asn, asc, ash, _stream(x))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# Synthesizer helpers
+# ---------------------------------------------------------------------------------------------------
+def sine_source(f0, noise, upp, sr, lin_w, lin_b, sine_amp=0.1, noise_std=0.003):
+    """f0: (T,) Hz; noise: (T*upp,) N(0,1) draws -> harmonic source (T*upp,) after l_linear + tanh."""
+    f0 = f0.contiguous().float()
+    noise = noise.contiguous().float()
+    t = f0.numel()
+    assert noise.numel() == t * upp
+    _check(f0, noise)
+    prefix = torch.empty(t, dtype=torch.float64, device=f0.device)
+    out = torch.empty(t * upp, dtype=torch.float32, device=f0.device)
+    _lib.call("aicg_sine_source", _ptr(f0), _ptr(noise), _ptr(prefix), _ptr(out), t, int(upp), float(sr), sine_amp,
+              noise_std, float(lin_w), float(lin_b), _stream(f0))
+    return out
+
+
+def gate_tanh_sigmoid(a, out=None):
+    """a: (N, 2C, T) contiguous -> tanh(a[:, :C]) * sigmoid(a[:, C:])."""
+    assert a.is_contiguous() and a.dim() == 3 and a.shape[1] % 2 == 0
+    n, c2, t = a.shape
+    if out is None:
+        out = torch.empty((n, c2 // 2, t), dtype=torch.float32, device=a.device)
+    assert out.is_contiguous()
+    _check(a, out)
+    _lib.call("aicg_gate_tanh_sigmoid", _ptr(a), _ptr(out), n, c2 // 2, t, _stream(a))
+    return out
+
+
+def prior_sample(stats, noise, scale):
+    """stats: (1, 2C, T) = [m; logs]; noise (1, C, T) -> m + exp(logs) * noise * scale."""
+    assert stats.is_contiguous() and noise.is_contiguous() and stats.shape[0] == 1
+    c, t = noise.shape[1], noise.shape[2]
+    assert stats.shape[1] == 2 * c and stats.shape[2] == t
+    out = torch.empty_like(noise)
+    _check(stats, noise)
+    _lib.call("aicg_prior_sample", _ptr(stats), _ptr(noise), _ptr(out), c, t, float(scale), _stream(stats))
+    return out
+
+
+def feats_prepare(feats, t_out, feats0=None, pitchf=None, protect=0.5):
+    """(Th, C) token-major features -> (1, C, t_out) channel-major, nearest x2 upsampled, protect-blended."""
+    feats = feats.contiguous()
+    th, c = feats.shape
+    out = torch.empty((1, c, t_out), dtype=torch.float32, device=feats.device)
+    if feats0 is not None:
+        feats0 = feats0.contiguous()
+        pitchf = pitchf.contiguous().float()
+        assert pitchf.numel() >= t_out
+    _check(feats, feats0, pitchf)
+    _lib.call("aicg_feats_prepare", _ptr(feats), _ptr(feats0), _ptr(pitchf), _ptr(out), th, c, int(t_out), float(protect),
+              _stream(feats))
+    return out
+
+
+def layernorm_ct(x, gamma, beta, res=None, out=None, eps=1e-5):
+    """LayerNorm over channels of contiguous (N, C, T); out = LN(x + res)."""
+    assert x.is_contiguous() and x.dim() == 3
+    n, c, t = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    if res is not None:
+        assert res.is_contiguous() and res.shape == x.shape
+    _check(x, res, gamma, beta, out)
+    _lib.call("aicg_layernorm_ct", _ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(out), n, c, t, float(eps), c * t, c * t,
+              c * t, _stream(x))
+    return out
+
+
+def rownorm_act(x, gamma, beta, act=ACT_NONE, eps=1e-5, out=None):
+    """x: (rows, T) contiguous: per-row (x - mean)/sqrt(var + eps) * gamma + beta, then act."""
+    assert x.is_contiguous() and x.dim() == 2
+    if out is None:
+        out = torch.empty_like(x)
+    _check(x, gamma, beta, out)
+    _lib.call("aicg_rownorm_act", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), x.shape[0], x.shape[1], float(eps), act,
+              _stream(x))
+    return out
+
+
+def attention(q, k, v, n_heads, relk=None, relv_emb=None, window=0, scale=1.0):
+    """q, k, v: (C, T) channel-major (rows may be slices of a fused QKV buffer; stride(1) == 1).
+    relk: (H, 2w+1, T) precomputed q.E^k (or None); relv_emb: (2w+1, D) for the relative value term."""
+    c, t = q.shape
+    d = c // n_heads
+    assert q.stride(1) == 1 and k.stride(1) == 1 and v.stride(1) == 1
+    o = torch.empty((c, t), dtype=torch.float32, device=q.device)
+    lse = torch.empty((n_heads, t), dtype=torch.float32, device=q.device) if relv_emb is not None else None
+    if relk is not None:
+        assert relk.is_contiguous() and relk.shape == (n_heads, 2 * window + 1, t)
+    _check(q, k, v, relk, relv_emb)
+    st = _stream(q)
+    _lib.call("aicg_attention", _ptr(q), _ptr(k), _ptr(v), _ptr(relk), _ptr(o), _ptr(lse), t, n_heads, d, window,
+              q.stride(0), k.stride(0), v.stride(0), o.stride(0), float(scale), st)
+    if relv_emb is not None:
+        relv_emb = relv_emb.contiguous()
+        _lib.call("aicg_attention_relv", _ptr(q), _ptr(k), _ptr(relk), _ptr(relv_emb), _ptr(lse), _ptr(o), t, n_heads, d,
+                  window, q.stride(0), k.stride(0), o.stride(0), float(scale), st)
+    return o

@@ -70,6 +70,93 @@ int aicg_istft_frames(const float* spec, float* frames, const float* window, con
 int aicg_istft_ola(const float* frames, const float* window, float* out, int n_sig, int L, int n_fft,
                    int hop, int n_frames, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Convolution as implicit GEMM on the matrix cores (fp32 MFMA, exact fp32 accumulate).
+ * One entry point for Conv1d / Conv2d / grouped / strided / dilated / 1x1 ("linear") layers:
+ *   torch.nn.Conv1d / Conv2d / Linear as used by infer_pack (src/infer_pack/models.py:445-516,
+ *   modules.py:188-213,299-312, attentions.py:190-193,387-388), rmvpe.ConvBlockRes (src/rmvpe.py:23-58),
+ *   fairseq HuBERT (call site src/vc_infer_pipeline.py:398-406) and the MDX-Net graph (src/mdx.py:74-77).
+ *
+ *   y[n,co,ho,wo] = [y +] out_scale * ( act( bias[co] + sum_{ci,kh,kw} W[co,ci,kh,kw] *
+ *                        pre_act(x[n, ci, ho*stride_h - pad_h + kh*dil_h, wo*stride_w - pad_w + kw*dil_w]) )
+ *                                       + res[n,co,ho,wo] )
+ * 1-D convolutions use H = KH = 1.  Strides are in elements; W is contiguous for x, y and res.
+ * Weights must be packed with the layout of aicovergen_amd.ops.pack_conv_weight (per group:
+ * [ceil(Cin_g/BKC)][KH*KW][BKC][Mpad], BKC = aicg_conv_bkc(KH*KW), Mpad = roundup(Cout_g, 32)).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct aicg_conv_desc {
+    int32_t N, Cin, H, W;
+    int32_t Cout, Ho, Wo;
+    int32_t KH, KW, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w, groups;
+    int64_t x_sn, x_sc, x_sh;
+    int64_t y_sn, y_sc, y_sh;
+    int64_t r_sn, r_sc, r_sh;
+    int32_t pre_act;   /* AICG_ACT_* applied to x while it is staged (e.g. leaky-ReLU of ResBlock1) */
+    float pre_slope;
+    int32_t act;       /* AICG_ACT_* applied to acc + bias */
+    float act_slope;
+    float out_scale;
+    int32_t accumulate; /* nonzero: add into y instead of overwriting */
+    int32_t res_before_act; /* nonzero: y = out_scale * act(acc + bias + res)  (e.g. emb_phone + emb_pitch -> lrelu) */
+} aicg_conv_desc;
+
+int aicg_conv_bkc(int taps);
+int aicg_conv_desc_size(void);
+int aicg_conv_forward(const aicg_conv_desc* desc, const float* x, const float* w_packed, const float* bias,
+                      const float* res, float* y, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Transposed convolution, second half: cols = (Cout*KH*KW, Cin) x input computed by aicg_conv_forward as a
+ * 1x1 GEMM, then gathered ("col2im") here:  torch.nn.ConvTranspose1d of GeneratorNSF.ups
+ * (src/infer_pack/models.py:453-463, :503) and ConvTranspose2d of rmvpe.ResDecoderBlock (src/rmvpe.py:147-155).
+ *   out[n,co,ho,wo] = act(bias[co] + sum_{kh,kw} cols[n,(co*KH+kh)*KW+kw,hi,wi]) + add[n,co,ho,wo],
+ *   hi = (ho + pad_h - kh)/stride_h when divisible and in range (same for w).  add may be NULL.
+ * ---------------------------------------------------------------------------------------------- */
+int aicg_col2im(const float* cols, const float* bias, const float* add, float* out, int N, int Cout, int Hi,
+                int Wi, int Ho, int Wo, int KH, int KW, int stride_h, int stride_w, int pad_h, int pad_w,
+                int act, float slope, int64_t o_sn, int64_t o_sc, int64_t o_sh, int64_t a_sn, int64_t a_sc,
+                int64_t a_sh, void* stream);
+
+/* NSF harmonic source: SineGen.forward + SourceModuleHnNSF.forward (src/infer_pack/models.py:320-370,414-419)
+ * with harmonic_num = 0.  f0: [T] Hz per frame; noise: [T*upp] standard-normal draws (the reference's
+ * torch.randn_like at :368, supplied by the caller so that both sides of a parity test see the same values);
+ * prefix_scratch: [T] doubles; out: [T*upp] = tanh(lin_w * (sine*uv + noise_amp*noise) + lin_b). */
+int aicg_sine_source(const float* f0, const float* noise, double* prefix_scratch, float* out, int T, int upp,
+                     float sr, float sine_amp, float noise_std, float lin_w, float lin_b, void* stream);
+
+/* commons.fused_add_tanh_sigmoid_multiply (src/infer_pack/commons.py:105-112); the conditioning slice is a
+ * per-channel constant for a (1,C,1) speaker embedding and is folded into the producing conv's bias.
+ * a: (N, 2C, T) -> out: (N, C, T). */
+int aicg_gate_tanh_sigmoid(const float* a, float* out, int N, int C, int64_t T, void* stream);
+
+/* z_p = m_p + exp(logs_p) * noise * scale (src/infer_pack/models.py:748); stats = [m_p ; logs_p] (2C, T). */
+int aicg_prior_sample(const float* stats, const float* noise, float* out, int C, int64_t T, float scale, void* stream);
+
+/* VC.vc feature plumbing (src/vc_infer_pipeline.py:433-452): nearest x2 upsample of the (Th, C) HuBERT
+ * features, protect blend with the voiced mask, written channel-major (C, T).  feats0/pitchf NULL = no protect. */
+int aicg_feats_prepare(const float* feats, const float* feats0, const float* pitchf, float* out, int Th, int C,
+                       int T, float protect, void* stream);
+
+/* modules.LayerNorm over channels of (N, C, T) maps with the residual add of attentions.Encoder fused
+ * (src/infer_pack/modules.py:29-32, attentions.py:67,71): out = LN_c(x + res) * gamma + beta. res may be NULL. */
+int aicg_layernorm_ct(const float* x, const float* res, const float* gamma, const float* beta, float* out, int N,
+                      int C, int64_t T, float eps, int64_t x_sn, int64_t r_sn, int64_t o_sn, void* stream);
+
+/* Per-row statistics over time + affine + activation: HuBERT feature extractor GroupNorm(512, 512) + GELU. */
+int aicg_rownorm_act(const float* x, const float* gamma, const float* beta, float* out, int rows, int64_t T,
+                     float eps, int act, void* stream);
+
+/* Fused softmax attention over channel-major q/k/v (H*D, T): o = softmax(scale * q^T k + relk) v.
+ * relk (H, 2*window+1, T) holds q_i . E^k_m (attentions.py:238-243) or is NULL (HuBERT).  lse (H, T) receives the
+ * log-sum-exp per query (needed by aicg_attention_relv) or is NULL.  D in {32, 64, 96, 128}. */
+int aicg_attention(const float* q, const float* k, const float* v, const float* relk, float* o, float* lse, int T,
+                   int H, int D, int window, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale,
+                   void* stream);
+/* o_i += sum_{|j-i|<=window} P_ij E^v_{j-i+window} (attentions.py:264-271); relv_emb: (2*window+1, D). */
+int aicg_attention_relv(const float* q, const float* k, const float* relk, const float* relv_emb,
+                        const float* lse, float* o, int T, int H, int D, int window, int64_t ldq, int64_t ldk,
+                        int64_t ldo, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,114 @@
+"""Implicit-GEMM convolution kernel vs torch.nn.functional (fp32).  Tolerance: relative RMS <= 1e-5
+(same fp32 products, different summation order -- the MFMA is a k-ordered fmaf chain)."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from aicovergen_amd import _lib, ops
+from conftest import rel_rms
+
+# (Cin, Cout, k, stride, pad, dil, groups, T)  -- shapes taken from the hot path
+CASES_1D = [
+    (32, 32, 3, 1, 1, 1, 1, 300),      # ResBlock1 stage 3 (modules.py:229-296)
+    (64, 64, 7, 1, 9, 3, 1, 260),      # ResBlock1 k7 d3
+    (48, 40, 11, 1, 25, 5, 1, 200),    # k11 d5 (ragged channel counts)
+    (192, 384, 5, 1, 2, 1, 1, 150),    # WN in_layer (modules.py:168-176)
+    (20, 70, 1, 1, 0, 1, 1, 333),      # 1x1 / linear
+    (16, 24, 10, 5, 0, 1, 1, 700),     # HuBERT feature extractor k10 s5
+    (32, 32, 3, 2, 0, 1, 1, 301),      # HuBERT k3 s2
+    (96, 96, 16, 1, 8, 1, 4, 130),     # grouped (HuBERT positional conv is k128 g16)
+    (130, 200, 3, 1, 1, 1, 1, 70),     # FFN k3, channels not multiples of the tile
+    (8, 1, 7, 1, 3, 1, 1, 500),        # conv_post: Cout = 1 (models.py:486)
+]
+
+
+def test_desc_struct_matches_c():
+    torch.manual_seed(0)
+    import conftest
+    conftest._bind("emu")
+    assert _lib.get().aicg_conv_desc_size() == ctypes.sizeof(ops.ConvDesc)
+
+
+@pytest.mark.parametrize("ci,co,k,s,p,d,g,T", CASES_1D)
+def test_conv1d(dev, ci, co, k, s, p, d, g, T):
+    torch.manual_seed(ci * 1000 + co)
+    if dev.big:
+        T *= 9
+    x = torch.randn(2, ci, T)
+    w = torch.randn(co, ci // g, k) * 0.1
+    b = torch.randn(co)
+    pc = ops.PackedConv(w, b, stride=s, padding=p, dilation=d, groups=g, device=dev.device)
+    y = ops.conv(dev.t(x), pc)
+    ref = F.conv1d(x, w, b, stride=s, padding=p, dilation=d, groups=g)
+    assert y.shape == ref.shape
+    assert rel_rms(y, ref) < 1e-5
+
+
+def test_conv_fused_resblock_step(dev):
+    """lrelu prologue + bias + residual + 1/3 accumulate: one ResBlock1 conv as GeneratorNSF uses it
+    (models.py:506-512: xs += resblock(x); x = xs / num_kernels)."""
+    torch.manual_seed(3)
+    T = 4000 if dev.big else 400
+    x = torch.randn(1, 64, T)
+    w = torch.randn(64, 64, 3) * 0.1
+    b = torch.randn(64)
+    y0 = torch.randn(1, 64, T)
+    pc = ops.PackedConv(w, b, padding=3, dilation=3, device=dev.device)
+    y = dev.t(y0.clone())
+    xd = dev.t(x)
+    ops.conv(xd, pc, res=xd, out=y, pre_act=ops.ACT_LRELU, pre_slope=0.1, out_scale=1 / 3, accumulate=True)
+    ref = y0 + (F.conv1d(F.leaky_relu(x, 0.1), w, b, padding=3, dilation=3) + x) / 3
+    assert rel_rms(y, ref) < 1e-5
+
+
+@pytest.mark.parametrize("act,fn", [(ops.ACT_GELU, F.gelu), (ops.ACT_RELU, F.relu), (ops.ACT_TANH, torch.tanh),
+                                    (ops.ACT_SIGMOID, torch.sigmoid)])
+def test_conv_epilogue_activations(dev, act, fn):
+    torch.manual_seed(5)
+    x = torch.randn(1, 40, 200)
+    w = torch.randn(24, 40, 3) * 0.2
+    b = torch.randn(24)
+    pc = ops.PackedConv(w, b, padding=1, device=dev.device)
+    y = ops.conv(dev.t(x), pc, act=act)
+    assert rel_rms(y, fn(F.conv1d(x, w, b, padding=1))) < 1e-5
+
+
+CASES_2D = [  # Cin, Cout, kh, kw, stride, pad, H, W
+    (16, 32, 3, 3, 1, 1, 40, 128),   # RMVPE level-0 ConvBlockRes (rmvpe.py:27-45)
+    (32, 16, 3, 3, 1, 1, 33, 4),     # deepest RMVPE level: only 4 mel columns left
+    (8, 8, 3, 3, 1, 1, 5, 20),
+    (24, 48, 2, 2, 2, 0, 16, 64),    # MDX-Net downsample 2x2 s2
+    (4, 48, 1, 1, 1, 0, 9, 96),      # MDX-Net first 1x1
+]
+
+
+@pytest.mark.parametrize("ci,co,kh,kw,s,p,H,W", CASES_2D)
+def test_conv2d(dev, ci, co, kh, kw, s, p, H, W):
+    torch.manual_seed(H * W)
+    x = torch.randn(2, ci, H, W)
+    w = torch.randn(co, ci, kh, kw) * 0.1
+    b = torch.randn(co)
+    pc = ops.PackedConv(w, b, stride=s, padding=p, device=dev.device)
+    y = ops.conv(dev.t(x), pc, act=ops.ACT_RELU)
+    assert rel_rms(y, F.relu(F.conv2d(x, w, b, stride=s, padding=p))) < 1e-5
+
+
+def test_conv_strided_views(dev):
+    """Outputs may be channel slices of a larger buffer (decoder concat without a copy, rmvpe.py:166)."""
+    torch.manual_seed(11)
+    x = torch.randn(1, 16, 10, 32)
+    w = torch.randn(8, 16, 3, 3) * 0.1
+    buf = dev.t(torch.zeros(1, 20, 10, 32))
+    pc = ops.PackedConv(w, None, padding=1, device=dev.device)
+    ops.conv(dev.t(x), pc, out=buf[:, 4:12])
+    assert rel_rms(buf[:, 4:12], F.conv2d(x, w, padding=1)) < 1e-5
+    assert buf[:, :4].abs().max() == 0 and buf[:, 12:].abs().max() == 0
+
+
+def test_conv_rejects_inconsistent_geometry(dev):
+    x = dev.t(torch.zeros(1, 8, 16))
+    pc = ops.PackedConv(torch.zeros(8, 8, 3), None, padding=1, device=dev.device)
+    with pytest.raises(AssertionError):
+        ops.conv(x, pc, out=dev.t(torch.zeros(1, 8, 15)))

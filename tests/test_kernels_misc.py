@@ -1,0 +1,147 @@
+"""Elementwise / normalisation / attention / transposed-conv kernels vs plain torch fp32 statements of the same
+reference ops (citations in include/aicg.h).  Tolerances: relative RMS <= 1e-5."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from aicovergen_amd import ops
+from conftest import rel_rms
+
+
+@pytest.mark.parametrize("ci,co,k,s,T", [(64, 32, 16, 10, 50), (32, 16, 4, 2, 77), (48, 24, 20, 10, 31), (16, 8, 24, 12, 20)])
+def test_conv_transpose1d(dev, ci, co, k, s, T):
+    """GeneratorNSF.ups (models.py:453-463): k16 s10 / k4 s2 (40k), k20 s10 (32k/48k), k24 s12 (48k)."""
+    torch.manual_seed(k * s)
+    if dev.big:
+        T *= 40
+    x = torch.randn(1, ci, T)
+    w = torch.randn(ci, co, k) * 0.1
+    b = torch.randn(co)
+    pt = ops.PackedConvTranspose(w, b, stride=s, padding=(k - s) // 2, device=dev.device)
+    add = torch.randn(1, co, pt.out_hw(1, T)[1])
+    y = ops.conv_transpose(dev.t(x), pt, add=dev.t(add), pre_act=ops.ACT_LRELU, pre_slope=0.1)
+    ref = F.conv_transpose1d(F.leaky_relu(x, 0.1), w, b, stride=s, padding=(k - s) // 2) + add
+    assert rel_rms(y, ref) < 1e-5
+
+
+def test_conv_transpose2d(dev):
+    """rmvpe.ResDecoderBlock.conv1 (rmvpe.py:147-155): 3x3 stride 2 pad 1 output_padding 1; MDX 2x2 stride 2."""
+    torch.manual_seed(2)
+    x = torch.randn(1, 16, 9, 8)
+    w = torch.randn(16, 8, 3, 3) * 0.1
+    pt = ops.PackedConvTranspose(w, None, stride=(2, 2), padding=(1, 1), output_padding=(1, 1), device=dev.device)
+    y = ops.conv_transpose(dev.t(x), pt, act=ops.ACT_RELU)
+    assert rel_rms(y, F.relu(F.conv_transpose2d(x, w, None, stride=2, padding=1, output_padding=1))) < 1e-5
+    w = torch.randn(16, 8, 2, 2) * 0.1
+    b = torch.randn(8)
+    pt = ops.PackedConvTranspose(w, b, stride=2, device=dev.device)
+    assert rel_rms(ops.conv_transpose(dev.t(x), pt), F.conv_transpose2d(x, w, b, stride=2)) < 1e-5
+
+
+def test_layernorm_ct(dev):
+    torch.manual_seed(3)
+    T = 3000 if dev.big else 130
+    x, r = torch.randn(2, 192, T), torch.randn(2, 192, T)
+    g, b = torch.rand(192) + 0.5, torch.randn(192)
+    y = ops.layernorm_ct(dev.t(x), dev.t(g), dev.t(b), res=dev.t(r))
+    ref = F.layer_norm((x + r).transpose(1, 2), (192,), g, b, 1e-5).transpose(1, 2)
+    assert rel_rms(y, ref) < 1e-5
+
+
+def test_rownorm_gelu(dev):
+    """HuBERT feature extractor layer 0: GroupNorm(512, 512) over time + GELU."""
+    torch.manual_seed(4)
+    T = 50000 if dev.big else 1000
+    x = torch.randn(7, T) * 3 + 1
+    g, b = torch.rand(7) + 0.5, torch.randn(7)
+    y = ops.rownorm_act(dev.t(x), dev.t(g), dev.t(b), act=ops.ACT_GELU)
+    assert rel_rms(y, F.gelu(F.group_norm(x.unsqueeze(0), 7, g, b, 1e-5))[0]) < 1e-5
+
+
+def test_gate_and_prior(dev):
+    torch.manual_seed(5)
+    a = torch.randn(1, 24, 50)
+    assert rel_rms(ops.gate_tanh_sigmoid(dev.t(a)), torch.tanh(a[:, :12]) * torch.sigmoid(a[:, 12:])) < 1e-6
+    st, nz = torch.randn(1, 8, 33), torch.randn(1, 4, 33)
+    assert rel_rms(ops.prior_sample(dev.t(st), dev.t(nz), 0.66666), st[:, :4] + torch.exp(st[:, 4:]) * nz * 0.66666) < 1e-6
+
+
+def test_feats_prepare(dev):
+    """vc_infer_pipeline.py:433-452: nearest x2, clip to p_len, protect blend (bit-exact: copies and one fma)."""
+    torch.manual_seed(6)
+    f, f0 = torch.randn(20, 70), torch.randn(20, 70)
+    pf = torch.rand(40) * 300
+    pf[5:15] = 0
+
+    def up(z):
+        return F.interpolate(z.t().unsqueeze(0), scale_factor=2)[0].t()
+
+    pff = pf.clone()
+    pff[pf > 0] = 1
+    pff[pf < 1] = 0.33
+    ref = (up(f) * pff[:, None] + up(f0) * (1 - pff[:, None]))[:39].t().unsqueeze(0)
+    y = ops.feats_prepare(dev.t(f), 39, dev.t(f0), dev.t(pf), 0.33)
+    assert rel_rms(y, ref) < 1e-6
+    assert torch.equal(ops.feats_prepare(dev.t(f), 40).cpu(), up(f).t().unsqueeze(0))
+
+
+def test_sine_source_matches_oracle(dev):
+    from oracle import synth
+    torch.manual_seed(7)
+    T, upp, sr = (600 if dev.big else 50), 400, 40000.0
+    f0 = 110 * 2 ** (torch.rand(T) * 2)
+    f0[10:20] = 0
+    noise = torch.randn(T * upp)
+    sd = {"dec.m_source.l_linear.weight": torch.tensor([[0.9]]), "dec.m_source.l_linear.bias": torch.tensor([0.01])}
+    ref = synth.sine_source(sd, f0[None], upp, sr, noise[None])[0, 0]
+    y = ops.sine_source(dev.t(f0), dev.t(noise), upp, sr, 0.9, 0.01)
+    assert (y.cpu() - ref).abs().max() < 2e-6
+
+
+@pytest.mark.parametrize("H,D,T,win", [(3, 64, 150, 0), (2, 96, 200, 10), (2, 32, 70, 4), (12, 64, 333, 0)])
+def test_attention(dev, H, D, T, win):
+    """Dense statement of attentions.MultiHeadAttention (banded relative keys/values) and of
+    plain softmax attention (HuBERT) vs the fused kernel."""
+    torch.manual_seed(T)
+    if dev.big:
+        T = T * 9 + 5
+    C = H * D
+    q, k, v = torch.randn(C, T) * 0.5, torch.randn(C, T) * 0.5, torch.randn(C, T)
+    qh, kh, vh = (z.view(H, D, T).transpose(1, 2) for z in (q, k, v))
+    sc = qh @ kh.transpose(1, 2)
+    relk = ev = None
+    if win:
+        ek, ev = torch.randn(2 * win + 1, D) * D ** -0.5, torch.randn(2 * win + 1, D) * D ** -0.5
+        rel = qh @ ek.t()
+        relk = rel.transpose(1, 2).contiguous()
+        i, j = torch.arange(T).view(T, 1), torch.arange(T).view(1, T)
+        m = j - i + win
+        band = (m >= 0) & (m <= 2 * win)
+        sc = sc + torch.where(band, rel.gather(2, m.clamp(0, 2 * win).expand(H, T, T)), torch.zeros(()))
+    pa = F.softmax(sc, -1)
+    out = pa @ vh
+    if win:
+        pb = torch.zeros(H, T, 2 * win + 1)
+        for mm in range(2 * win + 1):
+            jj = torch.arange(T) + mm - win
+            ok = (jj >= 0) & (jj < T)
+            pb[:, ok, mm] = pa[:, torch.arange(T)[ok], jj[ok]]
+        out = out + pb @ ev
+    ref = out.transpose(1, 2).reshape(C, T)
+    o = ops.attention(dev.t(q), dev.t(k), dev.t(v), H, relk=None if relk is None else dev.t(relk),
+                      relv_emb=None if ev is None else dev.t(ev), window=win)
+    assert rel_rms(o, ref) < 1e-5
+
+
+def test_attention_online_softmax_rescale(dev):
+    """A key whose score jumps far above every earlier tile forces the running-max rescale branch."""
+    torch.manual_seed(9)
+    H, D, T = 1, 64, 200
+    q, k, v = torch.randn(D, T) * 0.1, torch.randn(D, T) * 0.1, torch.randn(D, T)
+    k[:, 170] = q[:, 5] * 400.0  # spike: query 5 . key 170 >> everything else, 5 tiles in
+    qh, kh, vh = q.t(), k.t(), v.t()
+    ref = (F.softmax(qh @ kh.t(), -1) @ vh).t()
+    o = ops.attention(dev.t(q), dev.t(k), dev.t(v), H)
+    assert rel_rms(o, ref) < 1e-5
