@@ -35,6 +35,7 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
         case AICG_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
         case AICG_ACT_TANH: return tanhf(v);
         case AICG_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        case AICG_ACT_LOGCLAMP: return logf(fmaxf(v, slope));
         default: return v;
     }
 }

@@ -1,0 +1,203 @@
+// RMVPE-specific kernels (reference src/rmvpe.py): log-mel helpers, 2x2 average pooling, the bidirectional GRU
+// recurrence, and the salience -> f0 decode; plus the mel-scale coarse-pitch quantiser of VC.get_f0
+// (src/vc_infer_pipeline.py:361-368).  The convolutions of the DeepUnet run through conv.hip.
+#include "common.h"
+
+namespace aicg {
+
+// |re + i im| elementwise (rmvpe.py:314: magnitude = sqrt(real^2 + imag^2))
+__global__ void __launch_bounds__(256) cabs_kernel(const float* __restrict__ re, const float* __restrict__ im,
+                                                   float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        out[i] = sqrtf(re[i] * re[i] + im[i] * im[i]);
+}
+
+// y[n,c,:] = act(x[n,c,:] * scale[c] + shift[c])   (eval-mode BatchNorm2d on the network input, rmvpe.py:92)
+__global__ void __launch_bounds__(256) channel_affine_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, float* __restrict__ out,
+                                                             int C, long HW, long total, int act) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)((i / HW) % C);
+        out[i] = apply_act(x[i] * scale[c] + shift[c], act, 0.f);
+    }
+}
+
+// AvgPool2d(kernel 2x2, stride 2) (rmvpe.py:111); x may be a channel slice of a larger buffer
+__global__ void __launch_bounds__(256) avgpool2x2_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int C,
+                                                         int Ho, int Wo, long x_sn, long x_sc, long x_sh) {
+    const long total = (long)N * C * Ho * Wo;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int wo = (int)(i % Wo);
+        long t = i / Wo;
+        const int ho = (int)(t % Ho);
+        t /= Ho;
+        const int c = (int)(t % C);
+        const int n = (int)(t / C);
+        const float* p = x + (long)n * x_sn + (long)c * x_sc + (long)(2 * ho) * x_sh + 2 * wo;
+        out[i] = (p[0] + p[1] + p[x_sh] + p[x_sh + 1]) * 0.25f;
+    }
+}
+
+// ---- bidirectional GRU recurrence (torch.nn.GRU, 1 layer; rmvpe.py:11-20) --------------------------------------
+// gi: (2*3*Hd, T) = W_ih x + b_ih for [forward r,z,n ; reverse r,z,n], channel-major (computed by the conv kernel)
+// whh_t: (2, Hd, 3*Hd) = W_hh transposed per direction (k-major, so lane j reads unit-stride)
+// out: (2*Hd, T).  One workgroup per direction; h lives in LDS, W_hh streams from L2 each step.
+//   r = s(gi_r + W_hr h + b_hr); z = s(gi_z + W_hz h + b_hz); n = tanh(gi_n + r*(W_hn h + b_hn)); h = (1-z)*n + z*h
+template <int HD>
+__global__ void __launch_bounds__(3 * HD) gru_kernel(const float* __restrict__ gi, const float* __restrict__ whh_t,
+                                                     const float* __restrict__ bhh, float* __restrict__ out, long T) {
+    __shared__ float h[HD];
+    __shared__ float gh[3 * HD];
+    const int dir = blockIdx.x;
+    const int j = threadIdx.x;  // gate row 0..3*HD-1
+    const float* W = whh_t + (long)dir * HD * 3 * HD;
+    const float bj = bhh[dir * 3 * HD + j];
+    const float* gid = gi + (long)dir * 3 * HD * T;
+    float* od = out + (long)dir * HD * T;
+    if (j < HD) h[j] = 0.f;
+    __syncthreads();
+    for (long s = 0; s < T; ++s) {
+        const long t = dir == 0 ? s : T - 1 - s;
+        float acc = bj;
+#pragma unroll 8
+        for (int k = 0; k < HD; ++k) acc = fmaf(W[(long)k * 3 * HD + j], h[k], acc);
+        gh[j] = acc;
+        __syncthreads();
+        if (j < HD) {
+            const float r = 1.f / (1.f + expf(-(gid[(long)j * T + t] + gh[j])));
+            const float z = 1.f / (1.f + expf(-(gid[(long)(HD + j) * T + t] + gh[HD + j])));
+            const float n = tanhf(gid[(long)(2 * HD + j) * T + t] + r * gh[2 * HD + j]);
+            const float hn = (1.f - z) * n + z * h[j];
+            h[j] = hn;
+            od[(long)j * T + t] = hn;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- salience decode: RMVPE.to_local_average_cents + decode (rmvpe.py:359-364, 385-409) -----------------------
+// salience: (T, NB=360) row-major fp32.  One wave per frame: argmax by xor-shuffles (first maximum wins, like
+// np.argmax), then lane 0 forms the 9-bin float64 local average in numpy's pairwise order for n = 9:
+// ((a0+a1)+(a2+a3)) + ((a4+a5)+(a6+a7)) + a8  (np.sum over the contiguous last axis).
+__global__ void __launch_bounds__(256) salience_decode_kernel(const float* __restrict__ sal, double* __restrict__ cents,
+                                                              double* __restrict__ f0, int* __restrict__ center, long T,
+                                                              int NB, float thred) {
+    const int lane = threadIdx.x & 63;
+    const long frame = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (frame >= T) return;
+    const float* s = sal + frame * NB;
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    for (int k = lane; k < NB; k += 64) {
+        const float v = s[k];
+        if (v > best || (v == best && k < bidx)) { best = v; bidx = k; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bidx, o);
+        if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+    }
+    if (lane == 0) {
+        // np.sum(todo_salience * todo_cents_mapping, 1) is float64 (fp32 x fp64 products); np.sum(todo_salience, 1)
+        // stays float32; the division promotes the fp32 weight sum to float64.
+        double prod[9];
+        float wgt[9];
+        for (int i = 0; i < 9; ++i) {
+            const int k = bidx - 4 + i;  // index into the un-padded salience; outside -> padded zeros
+            const bool in = k >= 0 && k < NB;
+            const float sv = in ? s[k] : 0.f;
+            const double cm = in ? (20.0 * (double)k + 1997.3794084376191) : 0.0;  // cents_mapping, zero in the pad
+            prod[i] = (double)sv * cm;
+            wgt[i] = sv;
+        }
+        const double ps = (((prod[0] + prod[1]) + (prod[2] + prod[3])) + ((prod[4] + prod[5]) + (prod[6] + prod[7]))) + prod[8];
+        const float ws = (((wgt[0] + wgt[1]) + (wgt[2] + wgt[3])) + ((wgt[4] + wgt[5]) + (wgt[6] + wgt[7]))) + wgt[8];
+        double c = ps / (double)ws;
+        if (best <= thred) c = 0.0;  // devided[maxx <= thred] = 0
+        cents[frame] = c;
+        double f = 10.0 * pow(2.0, c / 1200.0);  // numpy: 10 * (2 ** (cents_pred / 1200))
+        if (f == 10.0) f = 0.0;  // f0[f0 == 10] = 0
+        f0[frame] = f;
+        if (center) center[frame] = bidx;
+    }
+}
+
+// ---- VC.get_f0 tail (vc_infer_pipeline.py:346,361-368): f0 *= 2^(key/12); mel quantise to 1..255, rint (half-even)
+__global__ void __launch_bounds__(256) f0_coarse_kernel(const double* __restrict__ f0_in, double factor, double* __restrict__ f0_out,
+                                                        long* __restrict__ coarse, long n, double mel_min, double mel_max) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const double f = f0_in[i] * factor;
+        f0_out[i] = f;
+        double mel = 1127.0 * log(1.0 + f / 700.0);
+        if (mel > 0.0) mel = (mel - mel_min) * 254.0 / (mel_max - mel_min) + 1.0;
+        if (mel <= 1.0) mel = 1.0;
+        if (mel > 255.0) mel = 255.0;
+        coarse[i] = (long)rint(mel);
+    }
+}
+
+static unsigned ew_grid2(long total) { return (unsigned)lmax(1, lmin((total + 255) / 256, 256L * 16)); }
+
+}  // namespace aicg
+
+using namespace aicg;
+
+extern "C" int aicg_complex_abs(const float* re, const float* im, float* out, int64_t n, void* stream) {
+    if (!re || !im || !out) return fail(AICG_E_ARG, "aicg_complex_abs: null pointer");
+    if (n == 0) return AICG_OK;
+    hipLaunchKernelGGL(cabs_kernel, dim3(ew_grid2(n)), dim3(256), 0, (hipStream_t)stream, re, im, out, (long)n);
+    return check_launch("cabs_kernel");
+}
+
+extern "C" int aicg_channel_affine(const float* x, const float* scale, const float* shift, float* out, int N, int C,
+                                   int64_t HW, int act, void* stream) {
+    if (!x || !scale || !shift || !out) return fail(AICG_E_ARG, "aicg_channel_affine: null pointer");
+    const long total = (long)N * C * HW;
+    if (total == 0) return AICG_OK;
+    hipLaunchKernelGGL(channel_affine_kernel, dim3(ew_grid2(total)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, out, C,
+                       (long)HW, total, act);
+    return check_launch("channel_affine_kernel");
+}
+
+extern "C" int aicg_avgpool2x2(const float* x, float* out, int N, int C, int H, int W, int64_t x_sn, int64_t x_sc,
+                               int64_t x_sh, void* stream) {
+    if (!x || !out) return fail(AICG_E_ARG, "aicg_avgpool2x2: null pointer");
+    const int Ho = H / 2, Wo = W / 2;
+    const long total = (long)N * C * Ho * Wo;
+    if (total == 0) return AICG_OK;
+    hipLaunchKernelGGL(avgpool2x2_kernel, dim3(ew_grid2(total)), dim3(256), 0, (hipStream_t)stream, x, out, N, C, Ho, Wo,
+                       (long)x_sn, (long)x_sc, (long)x_sh);
+    return check_launch("avgpool2x2_kernel");
+}
+
+extern "C" int aicg_gru_bidir(const float* gi, const float* whh_t, const float* bhh, float* out, int hidden, int64_t T,
+                              void* stream) {
+    if (!gi || !whh_t || !bhh || !out) return fail(AICG_E_ARG, "aicg_gru_bidir: null pointer");
+    if (T == 0) return AICG_OK;
+    if (hidden == 256)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gru_kernel<256>), dim3(2), dim3(768), 0, (hipStream_t)stream, gi, whh_t, bhh, out, (long)T);
+    else if (hidden == 64)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gru_kernel<64>), dim3(2), dim3(192), 0, (hipStream_t)stream, gi, whh_t, bhh, out, (long)T);
+    else
+        return fail(AICG_E_SHAPE, "aicg_gru_bidir: hidden size %d not instantiated (256, 64)", hidden);
+    return check_launch("gru_kernel");
+}
+
+extern "C" int aicg_salience_decode(const float* salience, double* cents, double* f0, int* center, int64_t T, int n_bins,
+                                    float thred, void* stream) {
+    if (!salience || !cents || !f0) return fail(AICG_E_ARG, "aicg_salience_decode: null pointer");
+    if (n_bins < 9) return fail(AICG_E_SHAPE, "aicg_salience_decode: need at least 9 bins");
+    if (T == 0) return AICG_OK;
+    hipLaunchKernelGGL(salience_decode_kernel, dim3((unsigned)ldiv_up(T, 4)), dim3(256), 0, (hipStream_t)stream, salience,
+                       cents, f0, center, (long)T, n_bins, thred);
+    return check_launch("salience_decode_kernel");
+}
+
+extern "C" int aicg_f0_coarse(const double* f0_in, double factor, double* f0_out, int64_t* coarse, int64_t n, double mel_min,
+                              double mel_max, void* stream) {
+    if (!f0_in || !f0_out || !coarse) return fail(AICG_E_ARG, "aicg_f0_coarse: null pointer");
+    if (n == 0) return AICG_OK;
+    hipLaunchKernelGGL(f0_coarse_kernel, dim3(ew_grid2(n)), dim3(256), 0, (hipStream_t)stream, f0_in, factor, f0_out,
+                       (long*)coarse, (long)n, mel_min, mel_max);
+    return check_launch("f0_coarse_kernel");
+}

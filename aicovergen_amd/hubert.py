@@ -1,0 +1,184 @@
+"""HuBERT-base content-feature extractor on the gfx950 kernels, exposing the slice of fairseq's HubertModel API
+that the reference uses: `load_hubert` builds it (reference src/rvc.py:98-109) and VC.vc calls
+`model.extract_features(source=, padding_mask=, output_layer=)` and `model.final_proj` (src/vc_infer_pipeline.py:398-406).
+
+Everything stays channel-major (C, T): the strided feature-extractor convs, the grouped positional conv and all
+Linear layers run through the implicit-GEMM conv kernel; attention through the fused softmax kernel (T x T never
+materialised); LayerNorms through layernorm_ct; layer-0 GroupNorm + GELU through rownorm_act.
+"""
+import io
+import pickle
+
+import torch
+
+from . import ops
+
+HUBERT_BASE = dict(conv_dim=512, conv_kernel=(10, 3, 3, 3, 3, 2, 2), conv_stride=(5, 2, 2, 2, 2, 2, 2), embed=768,
+                   heads=12, ffn=3072, layers=12, pos_k=128, pos_groups=16, final_dim=256)
+
+
+def _infer_cfg(sd):
+    """Hyper-parameters from tensor shapes (hubert_base.pt carries them in a fairseq cfg object we cannot unpickle)."""
+    n_conv = 0
+    kernels = []
+    while "feature_extractor.conv_layers.%d.0.weight" % n_conv in sd:
+        kernels.append(sd["feature_extractor.conv_layers.%d.0.weight" % n_conv].shape[2])
+        n_conv += 1
+    layers = 0
+    while "encoder.layers.%d.fc1.weight" % layers in sd:
+        layers += 1
+    v = sd["encoder.pos_conv.0.weight_v"]
+    E = v.shape[0]
+    strides = tuple([5] + [2] * (n_conv - 1))  # wav2vec2 / HuBERT default conv_feature_layers strides
+    return dict(conv_dim=sd["feature_extractor.conv_layers.0.0.weight"].shape[0], conv_kernel=tuple(kernels),
+                conv_stride=strides, embed=E, heads=max(1, E // 64), ffn=sd["encoder.layers.0.fc1.weight"].shape[0],
+                layers=layers, pos_k=v.shape[2], pos_groups=E // v.shape[1],
+                final_dim=sd["final_proj.weight"].shape[0] if "final_proj.weight" in sd else 0)
+
+
+class _FinalProj:
+    def __init__(self, owner):
+        self.owner = owner
+
+    def __call__(self, x):
+        """x: (1, T, embed) token-major -> (1, T, final_dim)   (v1 models: feats = model.final_proj(logits[0]))."""
+        P = self.owner._prepare()
+        y = ops.conv(x[0].t().contiguous().unsqueeze(0), P["final_proj"])
+        return y[0].t().contiguous().unsqueeze(0)
+
+
+class HubertModel:
+    def __init__(self, state_dict, cfg=None):
+        self._sd = {k: v.detach().to("cpu").float() for k, v in state_dict.items() if torch.is_tensor(v)}
+        self.cfg = dict(cfg) if cfg is not None else _infer_cfg(self._sd)
+        if "heads" in (cfg or {}):
+            self.cfg["heads"] = cfg["heads"]
+        self.device = torch.device("cpu")
+        self._p = None
+        self.final_proj = _FinalProj(self)
+
+    # torch.nn.Module-like surface used by load_hubert
+    def to(self, device):
+        self.device = torch.device(device)
+        self._p = None
+        return self
+
+    def half(self):
+        return self  # fp32 kernels (>= the reference's fp16 GPU path, src/rvc.py:103-104)
+
+    def float(self):
+        return self
+
+    def eval(self):
+        return self
+
+    def _prepare(self):
+        if self._p is not None:
+            return self._p
+        sd, cfg, dev = self._sd, self.cfg, self.device
+        P = {}
+        fe = []
+        for i, (k, s) in enumerate(zip(cfg["conv_kernel"], cfg["conv_stride"])):
+            w = sd["feature_extractor.conv_layers.%d.0.weight" % i]
+            b = sd.get("feature_extractor.conv_layers.%d.0.bias" % i)
+            if i == 0 and w.shape[1] == 1 and k == 2 * s:
+                # Conv1d(1 -> C, k = 2s, stride s) == Conv1d(s -> C, k = 2) over the s-phase view X[ph][q] = x[q*s + ph]
+                w2 = w.view(w.shape[0], 2, s).permute(0, 2, 1).contiguous()
+                fe.append(("phase", s, ops.PackedConv(w2, b, device=dev)))
+            else:
+                fe.append(("conv", s, ops.PackedConv(w, b, stride=s, device=dev)))
+        P["fe"] = fe
+        P["gn_w"] = sd["feature_extractor.conv_layers.0.2.weight"].to(dev)
+        P["gn_b"] = sd["feature_extractor.conv_layers.0.2.bias"].to(dev)
+        P["ln_w"], P["ln_b"] = sd["layer_norm.weight"].to(dev), sd["layer_norm.bias"].to(dev)
+        P["proj"] = ops.PackedConv(sd["post_extract_proj.weight"], sd["post_extract_proj.bias"], device=dev)
+        v, g = sd["encoder.pos_conv.0.weight_v"], sd["encoder.pos_conv.0.weight_g"]
+        wpos = v * (g / v.transpose(0, 2).flatten(1).norm(dim=1).view(1, 1, -1))  # weight_norm(dim=2) folded
+        P["pos"] = ops.PackedConv(wpos, sd["encoder.pos_conv.0.bias"], padding=cfg["pos_k"] // 2, groups=cfg["pos_groups"],
+                                  device=dev)
+        P["eln_w"], P["eln_b"] = sd["encoder.layer_norm.weight"].to(dev), sd["encoder.layer_norm.bias"].to(dev)
+        layers = []
+        for i in range(cfg["layers"]):
+            p = "encoder.layers.%d." % i
+            L = {"q": ops.PackedConv(sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.q_proj.bias"], device=dev),
+                 "kv": ops.PackedConv(torch.cat([sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.v_proj.weight"]], 0),
+                                      torch.cat([sd[p + "self_attn.k_proj.bias"], sd[p + "self_attn.v_proj.bias"]], 0), device=dev),
+                 "o": ops.PackedConv(sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"], device=dev),
+                 "fc1": ops.PackedConv(sd[p + "fc1.weight"], sd[p + "fc1.bias"], device=dev),
+                 "fc2": ops.PackedConv(sd[p + "fc2.weight"], sd[p + "fc2.bias"], device=dev),
+                 "ln1": (sd[p + "self_attn_layer_norm.weight"].to(dev), sd[p + "self_attn_layer_norm.bias"].to(dev)),
+                 "ln2": (sd[p + "final_layer_norm.weight"].to(dev), sd[p + "final_layer_norm.bias"].to(dev))}
+            layers.append(L)
+        P["layers"] = layers
+        if "final_proj.weight" in sd:
+            P["final_proj"] = ops.PackedConv(sd["final_proj.weight"], sd["final_proj.bias"], device=dev)
+        self._p = P
+        return P
+
+    def extract_features(self, source, padding_mask=None, mask=False, ret_conv=False, output_layer=None):
+        """fairseq HubertModel.extract_features for one un-padded waveform (1, N): returns (features (1, T, embed),
+        padding_mask).  `output_layer` is 1-based like fairseq's (12 for v2 models, 9 for v1)."""
+        P = self._prepare()
+        cfg, dev = self.cfg, self.device
+        assert source.dim() == 2 and source.shape[0] == 1, "one chunk at a time, as VC.vc calls it"
+        x = source.to(dev).float().contiguous()
+        n = x.shape[1]
+        cur = x.view(1, 1, n)
+        for i, (kind, s, pc) in enumerate(P["fe"]):
+            act = ops.ACT_NONE if i == 0 else ops.ACT_GELU
+            if kind == "phase":
+                to = (n - 2 * s) // s + 1
+                nq = (n + s - 1) // s
+                xp = torch.nn.functional.pad(cur.view(-1), (0, nq * s - n))          # zero fill to a multiple of s
+                cur = ops.conv(xp.view(nq, s).t().contiguous().unsqueeze(0), pc, act=act, out_len=to)
+            else:
+                cur = ops.conv(cur, pc, act=act)
+            if i == 0:  # GroupNorm(C, C): per-channel statistics over the whole chunk, then GELU
+                cur = ops.rownorm_act(cur[0], P["gn_w"], P["gn_b"], act=ops.ACT_GELU).unsqueeze(0)
+        T = cur.shape[2]
+        h = ops.layernorm_ct(cur, P["ln_w"], P["ln_b"])
+        h = ops.conv(h, P["proj"])
+        # x + GELU(SamePad(pos_conv(x))): the even kernel's extra last frame is simply not computed
+        h = ops.conv(h, P["pos"], act=ops.ACT_GELU, res=h, out_len=T)
+        h = ops.layernorm_ct(h, P["eln_w"], P["eln_b"])
+        E, H = cfg["embed"], cfg["heads"]
+        n_layers = cfg["layers"] if output_layer is None else min(output_layer, cfg["layers"])
+        for L in P["layers"][:n_layers]:
+            q = ops.conv(h, L["q"], out_scale=(E // H) ** -0.5)
+            kv = ops.conv(h, L["kv"])
+            a = ops.attention(q[0], kv[0, :E], kv[0, E:], H)
+            a = ops.conv(a.unsqueeze(0), L["o"])
+            h = ops.layernorm_ct(h, L["ln1"][0], L["ln1"][1], res=a)
+            f = ops.conv(h, L["fc1"], act=ops.ACT_GELU)
+            f = ops.conv(f, L["fc2"])
+            h = ops.layernorm_ct(h, L["ln2"][0], L["ln2"][1], res=f)
+        feats = h[0].t().contiguous().unsqueeze(0)  # (1, T, E) token-major, as fairseq returns it
+        return feats, padding_mask
+
+
+class _TolerantUnpickler(pickle.Unpickler):
+    """hubert_base.pt pickles fairseq / omegaconf config objects next to the tensors; those packages are not
+    needed to read the weights, so unknown classes are replaced by inert placeholders."""
+
+    def find_class(self, module, name):
+        try:
+            return super().find_class(module, name)
+        except Exception:
+            return type(name, (), {"__init__": lambda self, *a, **k: None, "__setstate__": lambda self, s: None})
+
+
+class _PickleModule:
+    Unpickler = _TolerantUnpickler
+    load = staticmethod(pickle.load)
+    __name__ = "tolerant_pickle"
+
+
+def load_state(model_path):
+    """Read a HuBERT checkpoint: fairseq format ({"model": state_dict, "cfg"/"args": ...}) or a bare state_dict."""
+    try:
+        ckpt = torch.load(model_path, map_location="cpu", weights_only=False)
+    except Exception:
+        ckpt = torch.load(model_path, map_location="cpu", weights_only=False, pickle_module=_PickleModule)
+    if isinstance(ckpt, dict) and "model" in ckpt and isinstance(ckpt["model"], dict):
+        return ckpt["model"]
+    return ckpt

@@ -259,7 +259,7 @@ class _SynthesizerBase:
         if self.use_f0:
             if noise_src is None:
                 noise_src = torch.randn(T * self.upp, device=x.device)  # reference: torch.randn_like (models.py:368)
-            har = ops.sine_source(f0.reshape(-1)[:T], noise_src.reshape(-1), self.upp, float(self.sr), P["lin_w"], P["lin_b"])
+            har = ops.sine_source(f0.reshape(-1)[:T], noise_src.to(x.device).reshape(-1), self.upp, float(self.sr), P["lin_w"], P["lin_b"])
         pre_bias = ops.conv(g, P["cond"], res=P["conv_pre_bias"])  # conv_pre.bias + cond(g), per-channel constant
         x = ops.conv(x, P["conv_pre"], bias=pre_bias.reshape(-1))
         nk = len(self.resblock_kernel_sizes)

@@ -182,7 +182,7 @@ def _as4d(t):
 
 
 def conv(x, pc, res=None, out=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NONE, act_slope=0.0, out_scale=1.0,
-         accumulate=False, bias=None, res_before_act=False):
+         accumulate=False, bias=None, res_before_act=False, out_len=None):
     """y = [y +] out_scale * (act(conv(pre_act(x)) + bias) + res).  x: (N,C,T) or (N,C,H,W), last dim contiguous;
     views with arbitrary batch/channel/row strides are accepted for x, res and out."""
     is1d = x.dim() == 3
@@ -191,6 +191,9 @@ def conv(x, pc, res=None, out=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NON
     assert c == pc.cin, "conv: input has %d channels, layer expects %d" % (c, pc.cin)
     assert x4.stride(3) == 1 or w == 1
     ho, wo = pc.out_hw(h, w)
+    if out_len is not None:  # compute only the first out_len columns (e.g. SamePad of an even kernel)
+        assert out_len <= wo
+        wo = out_len
     if out is None:
         out = torch.empty((n, pc.cout, wo) if is1d else (n, pc.cout, ho, wo), dtype=torch.float32, device=x.device)
         assert not accumulate
@@ -368,3 +371,69 @@ def attention(q, k, v, n_heads, relk=None, relv_emb=None, window=0, scale=1.0):
         _lib.call("aicg_attention_relv", _ptr(q), _ptr(k), _ptr(relk), _ptr(relv_emb), _ptr(lse), _ptr(o), t, n_heads, d,
                   window, q.stride(0), k.stride(0), o.stride(0), float(scale), st)
     return o
+
+
+# ---------------------------------------------------------------------------------------------------
+# RMVPE helpers
+# ---------------------------------------------------------------------------------------------------
+ACT_LOGCLAMP = 6
+
+
+def complex_abs(re, im):
+    assert re.is_contiguous() and im.is_contiguous() and re.shape == im.shape
+    out = torch.empty_like(re)
+    _check(re, im)
+    _lib.call("aicg_complex_abs", _ptr(re), _ptr(im), _ptr(out), re.numel(), _stream(re))
+    return out
+
+
+def channel_affine(x, scale, shift, act=ACT_NONE):
+    assert x.is_contiguous() and x.dim() >= 2
+    n, c = x.shape[0], x.shape[1]
+    hw = x.numel() // (n * c)
+    out = torch.empty_like(x)
+    _check(x, scale, shift)
+    _lib.call("aicg_channel_affine", _ptr(x), _ptr(scale), _ptr(shift), _ptr(out), n, c, hw, act, _stream(x))
+    return out
+
+
+def avgpool2x2(x):
+    n, c, h, w = x.shape
+    assert x.stride(3) == 1
+    out = torch.empty((n, c, h // 2, w // 2), dtype=torch.float32, device=x.device)
+    _check(x)
+    _lib.call("aicg_avgpool2x2", _ptr(x), _ptr(out), n, c, h, w, x.stride(0), x.stride(1), x.stride(2), _stream(x))
+    return out
+
+
+def gru_bidir(gi, whh_t, bhh, hidden):
+    """gi: (6*hidden, T) channel-major input projections -> (2*hidden, T)."""
+    assert gi.is_contiguous() and gi.shape[0] == 6 * hidden
+    t = gi.shape[1]
+    out = torch.empty((2 * hidden, t), dtype=torch.float32, device=gi.device)
+    _check(gi, whh_t, bhh)
+    _lib.call("aicg_gru_bidir", _ptr(gi), _ptr(whh_t), _ptr(bhh), _ptr(out), hidden, t, _stream(gi))
+    return out
+
+
+def salience_decode(salience, thred=0.03, want_center=False):
+    """salience (T, 360) fp32 row-major -> (cents float64 (T,), f0 float64 (T,)[, argmax int32 (T,)])."""
+    salience = salience.contiguous().float()
+    t, nb = salience.shape
+    cents = torch.empty(t, dtype=torch.float64, device=salience.device)
+    f0 = torch.empty(t, dtype=torch.float64, device=salience.device)
+    center = torch.empty(t, dtype=torch.int32, device=salience.device) if want_center else None
+    _check(salience)
+    _lib.call("aicg_salience_decode", _ptr(salience), _ptr(cents), _ptr(f0), _ptr(center), t, nb, float(thred), _stream(salience))
+    return (cents, f0, center) if want_center else (cents, f0)
+
+
+def f0_coarse(f0, factor, mel_min, mel_max):
+    """f0 float64 (n,) -> (f0 * factor float64, coarse int64 in [1, 255])."""
+    f0 = f0.contiguous().double()
+    out = torch.empty_like(f0)
+    coarse = torch.empty(f0.shape, dtype=torch.int64, device=f0.device)
+    _check(f0)
+    _lib.call("aicg_f0_coarse", _ptr(f0), float(factor), _ptr(out), _ptr(coarse), f0.numel(), float(mel_min), float(mel_max),
+              _stream(f0))
+    return out, coarse

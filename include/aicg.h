@@ -34,6 +34,7 @@ extern "C" {
 #define AICG_ACT_GELU 3  /* exact erf form (fairseq / HF HuBERT "gelu") */
 #define AICG_ACT_TANH 4
 #define AICG_ACT_SIGMOID 5
+#define AICG_ACT_LOGCLAMP 6 /* log(max(v, slope)): log-mel of rmvpe.MelSpectrogram (src/rmvpe.py:324) */
 
 const char* aicg_last_error(void);
 /* ABI version; bumped whenever a signature changes */
@@ -156,6 +157,31 @@ int aicg_attention(const float* q, const float* k, const float* v, const float* 
 int aicg_attention_relv(const float* q, const float* k, const float* relk, const float* relv_emb,
                         const float* lse, float* o, int T, int H, int D, int window, int64_t ldq, int64_t ldk,
                         int64_t ldo, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * RMVPE f0 estimator helpers (reference src/rmvpe.py)
+ * ---------------------------------------------------------------------------------------------- */
+/* magnitude = sqrt(re^2 + im^2) (src/rmvpe.py:314) */
+int aicg_complex_abs(const float* re, const float* im, float* out, int64_t n, void* stream);
+/* eval-mode BatchNorm2d on the network input as a per-channel affine (src/rmvpe.py:74,92) */
+int aicg_channel_affine(const float* x, const float* scale, const float* shift, float* out, int N, int C,
+                        int64_t HW, int act, void* stream);
+/* nn.AvgPool2d(kernel_size=(2,2)) (src/rmvpe.py:111); x: (N,C,H,W) view with strides, out contiguous (N,C,H/2,W/2) */
+int aicg_avgpool2x2(const float* x, float* out, int N, int C, int H, int W, int64_t x_sn, int64_t x_sc,
+                    int64_t x_sh, void* stream);
+/* Bidirectional single-layer nn.GRU recurrence (src/rmvpe.py:11-20).  gi: (2*3*hidden, T) input projections
+ * W_ih x + b_ih for [forward r,z,n ; reverse r,z,n]; whh_t: (2, hidden, 3*hidden) = W_hh^T per direction;
+ * bhh: (2*3*hidden); out: (2*hidden, T) = [forward h ; reverse h]. */
+int aicg_gru_bidir(const float* gi, const float* whh_t, const float* bhh, float* out, int hidden, int64_t T,
+                   void* stream);
+/* RMVPE.decode / to_local_average_cents (src/rmvpe.py:359-364,385-409).  salience: (T, n_bins) row-major fp32;
+ * cents, f0: (T) float64 (bit-equal to the numpy reference given identical salience); center: (T) argmax or NULL. */
+int aicg_salience_decode(const float* salience, double* cents, double* f0, int* center, int64_t T, int n_bins,
+                         float thred, void* stream);
+/* VC.get_f0 tail (src/vc_infer_pipeline.py:346,361-368): f0_out = f0_in * factor; coarse = rint(clamp(mel-scale
+ * affine map to [1,255])) as int64 (np.rint, round-half-even). */
+int aicg_f0_coarse(const double* f0_in, double factor, double* f0_out, int64_t* coarse, int64_t n, double mel_min,
+                   double mel_max, void* stream);
 
 #ifdef __cplusplus
 }

@@ -110,3 +110,117 @@ def synth_checkpoint(cfg=SYNTH_CFG_40K_V2, seed=1234):
     """The on-disk dict reference src/rvc.py:113-120 expects from torch.load(model.pth)."""
     return {"config": list(cfg), "weight": synth_state_dict(cfg, seed), "f0": 1, "version": "v2",
             "info": "seeded-random", "sr": "40k"}
+
+
+# ---------------------------------------------------------------------------------------------------
+# HuBERT (fairseq 0.12.2 `HubertModel`, hubert_base.pt key names) -- not vendored by the reference:
+# architecture restated from fairseq models/hubert/hubert.py + models/wav2vec/wav2vec2.py and cross-checked
+# against transformers.HubertModel (same hyper-parameters) in tests/golden/make_golden.py.
+# ---------------------------------------------------------------------------------------------------
+HUBERT_BASE = dict(conv_dim=512, conv_kernel=(10, 3, 3, 3, 3, 2, 2), conv_stride=(5, 2, 2, 2, 2, 2, 2), embed=768,
+                   heads=12, ffn=3072, layers=12, pos_k=128, pos_groups=16, final_dim=256)
+HUBERT_TINY = dict(conv_dim=32, conv_kernel=(10, 3, 3, 3, 3, 2, 2), conv_stride=(5, 2, 2, 2, 2, 2, 2), embed=64,
+                   heads=2, ffn=128, layers=2, pos_k=16, pos_groups=4, final_dim=16)
+
+
+def hubert_state_dict(cfg=HUBERT_BASE, seed=1234):
+    g = _Gen(seed)
+    sd = {}
+    cd, E = cfg["conv_dim"], cfg["embed"]
+    cin = 1
+    for i, k in enumerate(cfg["conv_kernel"]):
+        sd["feature_extractor.conv_layers.%d.0.weight" % i] = g.normal(cd, cin, k, std=math.sqrt(2.0 / (cin * k)))
+        cin = cd
+    sd["feature_extractor.conv_layers.0.2.weight"] = g.uniform(cd, lo=0.8, hi=1.2)   # GroupNorm(cd, cd) affine
+    sd["feature_extractor.conv_layers.0.2.bias"] = g.normal(cd, std=0.1)
+    sd["layer_norm.weight"] = g.uniform(cd, lo=0.8, hi=1.2)
+    sd["layer_norm.bias"] = g.normal(cd, std=0.1)
+    sd["post_extract_proj.weight"] = g.normal(E, cd, std=1.0 / math.sqrt(cd))
+    sd["post_extract_proj.bias"] = g.normal(E, std=0.05)
+    pk, pg = cfg["pos_k"], cfg["pos_groups"]
+    v = g.normal(E, E // pg, pk, std=1.0 / math.sqrt(pk * E // pg))
+    sd["encoder.pos_conv.0.weight_v"] = v
+    # weight_norm(dim=2): one gain per kernel tap, norm over the other two dims
+    sd["encoder.pos_conv.0.weight_g"] = v.transpose(0, 2).flatten(1).norm(dim=1).view(1, 1, pk) * g.uniform(1, 1, pk, lo=0.7, hi=1.3)
+    sd["encoder.pos_conv.0.bias"] = g.normal(E, std=0.05)
+    sd["encoder.layer_norm.weight"] = g.uniform(E, lo=0.8, hi=1.2)
+    sd["encoder.layer_norm.bias"] = g.normal(E, std=0.1)
+    for i in range(cfg["layers"]):
+        p = "encoder.layers.%d." % i
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            sd[p + "self_attn.%s.weight" % n] = g.normal(E, E, std=(1.6 if n in ("q_proj", "k_proj") else 1.0) / math.sqrt(E))
+            sd[p + "self_attn.%s.bias" % n] = g.normal(E, std=0.05)
+        sd[p + "self_attn_layer_norm.weight"] = g.uniform(E, lo=0.8, hi=1.2)
+        sd[p + "self_attn_layer_norm.bias"] = g.normal(E, std=0.1)
+        sd[p + "fc1.weight"] = g.normal(cfg["ffn"], E, std=1.0 / math.sqrt(E))
+        sd[p + "fc1.bias"] = g.normal(cfg["ffn"], std=0.05)
+        sd[p + "fc2.weight"] = g.normal(E, cfg["ffn"], std=1.0 / math.sqrt(cfg["ffn"]))
+        sd[p + "fc2.bias"] = g.normal(E, std=0.05)
+        sd[p + "final_layer_norm.weight"] = g.uniform(E, lo=0.8, hi=1.2)
+        sd[p + "final_layer_norm.bias"] = g.normal(E, std=0.1)
+    sd["final_proj.weight"] = g.normal(cfg["final_dim"], E, std=1.0 / math.sqrt(E))
+    sd["final_proj.bias"] = g.normal(cfg["final_dim"], std=0.05)
+    return {k: v.contiguous().float() for k, v in sd.items()}
+
+
+# ---------------------------------------------------------------------------------------------------
+# RMVPE E2E (reference src/rmvpe.py:221-258): DeepUnet + BiGRU(384 -> 256) + Linear(512 -> 360)
+# ---------------------------------------------------------------------------------------------------
+RMVPE_FULL = dict(n_blocks=4, en_de_layers=5, inter_layers=4, en_out_channels=16)
+RMVPE_TINY = dict(n_blocks=1, en_de_layers=5, inter_layers=1, en_out_channels=2)
+
+
+def _bn(sd, g, name, c):
+    sd[name + ".weight"] = g.uniform(c, lo=0.8, hi=1.2)
+    sd[name + ".bias"] = g.normal(c, std=0.05)
+    sd[name + ".running_mean"] = g.normal(c, std=0.05)
+    sd[name + ".running_var"] = g.uniform(c, lo=0.8, hi=1.25)
+    sd[name + ".num_batches_tracked"] = torch.tensor(1)
+
+
+def _conv_block_res(sd, g, name, cin, cout, gain):
+    """ConvBlockRes (rmvpe.py:23-58).  The residual path gets a small gain so that ~60 stacked blocks with
+    un-calibrated BatchNorm statistics keep O(1) activations (SURVEY 7 'hard parts')."""
+    sd[name + ".conv.0.weight"] = g.normal(cout, cin, 3, 3, std=math.sqrt(2.0 / (cin * 9)))
+    _bn(sd, g, name + ".conv.1", cout)
+    sd[name + ".conv.3.weight"] = g.normal(cout, cout, 3, 3, std=gain * math.sqrt(2.0 / (cout * 9)))
+    _bn(sd, g, name + ".conv.4", cout)
+    if cin != cout:
+        sd[name + ".shortcut.weight"] = g.normal(cout, cin, 1, 1, std=1.0 / math.sqrt(cin))
+        sd[name + ".shortcut.bias"] = g.normal(cout, std=0.05)
+
+
+def rmvpe_state_dict(cfg=RMVPE_FULL, seed=1234):
+    g = _Gen(seed)
+    sd = {}
+    nb, nl, ni, c0 = cfg["n_blocks"], cfg["en_de_layers"], cfg["inter_layers"], cfg["en_out_channels"]
+    gain = 0.35
+    _bn(sd, g, "unet.encoder.bn", 1)
+    cin, cout = 1, c0
+    for i in range(nl):
+        for b in range(nb):
+            _conv_block_res(sd, g, "unet.encoder.layers.%d.conv.%d" % (i, b), cin if b == 0 else cout, cout, gain)
+        cin, cout = cout, cout * 2
+    # after the loop: cin = c0 * 2^(nl-1) (deepest encoder width), cout = 2 * cin
+    for i in range(ni):
+        for b in range(nb):
+            _conv_block_res(sd, g, "unet.intermediate.layers.%d.conv.%d" % (i, b), cin if (i == 0 and b == 0) else cout, cout, gain)
+    dc = cout
+    for i in range(nl):
+        oc = dc // 2
+        sd["unet.decoder.layers.%d.conv1.0.weight" % i] = g.normal(dc, oc, 3, 3, std=math.sqrt(2.0 / (dc * 9 / 4)))
+        _bn(sd, g, "unet.decoder.layers.%d.conv1.1" % i, oc)
+        for b in range(nb):
+            _conv_block_res(sd, g, "unet.decoder.layers.%d.conv2.%d" % (i, b), oc * 2 if b == 0 else oc, oc, gain)
+        dc = oc
+    sd["cnn.weight"] = g.normal(3, c0, 3, 3, std=1.0 / math.sqrt(c0 * 9))
+    sd["cnn.bias"] = g.normal(3, std=0.05)
+    hid = 256
+    for suf in ("", "_reverse"):
+        sd["fc.0.gru.weight_ih_l0" + suf] = g.uniform(3 * hid, 384, lo=-1, hi=1) / math.sqrt(hid) * 2.0
+        sd["fc.0.gru.weight_hh_l0" + suf] = g.uniform(3 * hid, hid, lo=-1, hi=1) / math.sqrt(hid)
+        sd["fc.0.gru.bias_ih_l0" + suf] = g.uniform(3 * hid, lo=-1, hi=1) / math.sqrt(hid)
+        sd["fc.0.gru.bias_hh_l0" + suf] = g.uniform(3 * hid, lo=-1, hi=1) / math.sqrt(hid)
+    sd["fc.1.weight"] = g.normal(360, 512, std=3.0 / math.sqrt(512))
+    sd["fc.1.bias"] = g.normal(360, std=0.5) - 2.0
+    return {k: (v.contiguous().float() if v.is_floating_point() else v) for k, v in sd.items()}

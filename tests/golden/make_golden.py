@@ -55,7 +55,64 @@ def make_synth(name, cfg, T, seed):
     print(name, "audio", tuple(o.shape), float(o.abs().max()), float(o.pow(2).mean().sqrt()))
 
 
+def make_hubert(name, cfg, seconds, seed):
+    """HuBERT: fairseq is absent, so the pin is transformers.HubertModel with the same weights (key-mapped)."""
+    from transformers import HubertConfig, HubertModel
+    from oracle import hubert as ohub
+    from oracle import weights
+    from oracle.inputs import vocal_like
+    sd = weights.hubert_state_dict(cfg, seed)
+    hc = HubertConfig(hidden_size=cfg["embed"], num_hidden_layers=cfg["layers"], num_attention_heads=cfg["heads"],
+                      intermediate_size=cfg["ffn"], conv_dim=(cfg["conv_dim"],) * 7, num_conv_pos_embeddings=cfg["pos_k"],
+                      num_conv_pos_embedding_groups=cfg["pos_groups"])
+    m = HubertModel(hc).eval()
+    r = m.load_state_dict(ohub.to_hf_state_dict(sd), strict=False)
+    assert r.missing_keys == ["masked_spec_embed"] and not r.unexpected_keys, r
+    wav = torch.from_numpy(vocal_like(seconds, 16000, seed + 2)).unsqueeze(0)
+    with torch.no_grad():
+        out = m(wav, output_hidden_states=True)
+    l9 = out.hidden_states[min(9, cfg["layers"])]
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), seed=np.array([seed]), seconds=np.array([seconds]),
+                        last=out.last_hidden_state[0].numpy(), layer9=l9[0].numpy())
+    print(name, tuple(out.last_hidden_state.shape))
+
+
+def make_rmvpe(name, cfg, seconds, seed):
+    import types
+    from oracle import rmvpe as orm
+    from oracle import weights
+    from oracle.inputs import vocal_like
+    lib = types.ModuleType("librosa")
+    lib.filters = types.ModuleType("librosa.filters")
+    lib.filters.mel = lambda sr, n_fft, n_mels, fmin, fmax, htk: orm.mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
+    sys.modules.setdefault("librosa", lib)
+    sys.modules.setdefault("librosa.filters", lib.filters)
+    sys.path.insert(0, REF)
+    import rmvpe as ref
+    sd = weights.rmvpe_state_dict(cfg, seed)
+    model = ref.E2E(cfg["n_blocks"], 1, (2, 2), cfg["en_de_layers"], cfg["inter_layers"], 1, cfg["en_out_channels"])
+    model.load_state_dict(sd)
+    model.eval()
+    r = ref.RMVPE.__new__(ref.RMVPE)
+    r.model, r.is_half, r.device, r.resample_kernel = model, False, "cpu", {}
+    r.mel_extractor = ref.MelSpectrogram(False, 128, 16000, 1024, 160, None, 30, 8000)
+    r.cents_mapping = np.pad(20 * np.arange(360) + 1997.3794084376191, (4, 4))
+    audio = vocal_like(seconds, 16000, seed + 3)
+    f0 = r.infer_from_audio(audio, thred=0.03)
+    with torch.no_grad():
+        mel = r.mel_extractor(torch.from_numpy(audio)[None], center=True)
+        hidden = r.mel2hidden(mel)[0].numpy()
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), seed=np.array([seed]), seconds=np.array([seconds]),
+                        f0=f0, hidden=hidden.astype(np.float16 if hidden.size > 60000 else np.float32),
+                        argmax=hidden.argmax(1).astype(np.int16), mel=mel[0].numpy().astype(np.float32))
+    print(name, hidden.shape, float((f0 > 0).mean()))
+
+
 if __name__ == "__main__":
     from oracle import weights
     make_synth("synth_tiny_T24", weights.SYNTH_CFG_TINY, 24, 1234)
     make_synth("synth_40k_T16", weights.SYNTH_CFG_40K_V2, 16, 1234)
+    make_hubert("hubert_tiny_1s", weights.HUBERT_TINY, 1.0, 1234)
+    make_hubert("hubert_base_1s", weights.HUBERT_BASE, 1.0, 1234)
+    make_rmvpe("rmvpe_tiny_1s", weights.RMVPE_TINY, 1.0, 1234)
+    make_rmvpe("rmvpe_full_1s", weights.RMVPE_FULL, 1.0, 1234)

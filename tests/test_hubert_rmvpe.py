@@ -1,0 +1,131 @@
+"""HuBERT feature extractor and RMVPE f0 estimator on the HIP kernels vs the oracle restatements
+(oracle/hubert.py pinned against transformers.HubertModel, oracle/rmvpe.py pinned against the reference's own
+src/rmvpe.py -- see tests/test_oracle_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from aicovergen_amd import ops
+from aicovergen_amd.hubert import HubertModel, _infer_cfg
+from aicovergen_amd.rmvpe import RMVPE, mel_filterbank
+from conftest import rel_rms
+from oracle import hubert as ohub
+from oracle import rmvpe as orm
+from oracle import weights
+from oracle.inputs import vocal_like
+
+
+def test_hubert_tiny_matches_oracle(dev):
+    cfg = weights.HUBERT_TINY
+    sd = weights.hubert_state_dict(cfg, 1234)
+    m = HubertModel(sd, cfg).to(dev.device)
+    torch.manual_seed(0)
+    wav = torch.randn(1, 8123) * 0.3
+    y, pm = m.extract_features(source=wav, padding_mask=torch.zeros(wav.shape, dtype=torch.bool), output_layer=12)
+    with torch.no_grad():
+        ref = ohub.extract_features(sd, cfg, wav, 12)
+    assert y.shape == ref.shape == (1, (8123 - 400) // 320 + 1, cfg["embed"])
+    assert rel_rms(y, ref) < 1e-4
+    assert rel_rms(m.final_proj(y), ohub.final_proj(sd, ref)) < 1e-4
+    y1, _ = m.extract_features(source=wav, padding_mask=None, output_layer=1)
+    with torch.no_grad():
+        assert rel_rms(y1, ohub.extract_features(sd, cfg, wav, 1)) < 1e-4
+
+
+def test_hubert_cfg_inferred_from_shapes():
+    sd = weights.hubert_state_dict(weights.HUBERT_TINY, 1)
+    cfg = _infer_cfg(sd)
+    for k in ("conv_dim", "conv_kernel", "embed", "ffn", "layers", "pos_k", "pos_groups", "final_dim"):
+        assert cfg[k] == weights.HUBERT_TINY[k], k
+
+
+@pytest.mark.gpu
+def test_hubert_base_matches_oracle():
+    """HuBERT-base sized model (94 M parameters), 4 s of audio, layer 12 and layer 9 + final_proj (v1 path)."""
+    import conftest
+    conftest._bind("hip")
+    cfg = weights.HUBERT_BASE
+    sd = weights.hubert_state_dict(cfg, 1234)
+    m = HubertModel(sd, cfg).to("cuda:0")
+    wav = torch.from_numpy(vocal_like(4.0, 16000, seed=3)).unsqueeze(0)
+    y, _ = m.extract_features(source=wav, padding_mask=None, output_layer=12)
+    with torch.no_grad():
+        ref = ohub.extract_features(sd, cfg, wav, 12)
+        ref9 = ohub.final_proj(sd, ohub.extract_features(sd, cfg, wav, 9))
+    assert rel_rms(y, ref) < 1e-4
+    y9, _ = m.extract_features(source=wav, padding_mask=None, output_layer=9)
+    assert rel_rms(m.final_proj(y9), ref9) < 1e-4
+
+
+def test_mel_filterbank_table():
+    fb = mel_filterbank()
+    assert fb.shape == (128, 513) and fb.dtype == np.float32
+    assert np.array_equal(fb, orm.mel_filterbank())
+    assert (fb >= 0).all() and (fb.sum(1) > 0).all()
+
+
+def test_rmvpe_tiny_matches_oracle(dev):
+    sd = weights.rmvpe_state_dict(weights.RMVPE_TINY, 1234)
+    r = RMVPE(None, False, dev.device, state_dict=sd)
+    audio = vocal_like(1.0, 16000, seed=5)
+    mel = r.mel_extractor(torch.from_numpy(audio)[None])
+    omel = orm.log_mel(torch.from_numpy(audio)[None], torch.from_numpy(orm.mel_filterbank()))
+    assert mel.shape == omel.shape == (1, 128, 101)
+    assert (mel.cpu() - omel).abs().max() < 2e-4      # log of clamped small mels amplifies fp32 FFT differences
+    hid = r.mel2hidden(mel)[0].cpu().numpy()
+    of0, ohid = orm.infer_from_audio(sd, audio, 0.03)
+    assert hid.shape == ohid.shape == (101, 360)
+    assert np.abs(hid - ohid).max() < 1e-4
+    f0 = r.infer_from_audio(audio, 0.03)
+    agree = hid.argmax(1) == ohid.argmax(1)
+    assert agree.mean() > 0.98, "salience argmax agreement %.3f" % agree.mean()
+    assert np.abs(f0 - of0)[agree].max() < 1e-2
+
+
+def test_salience_decode_bit_exact(dev):
+    """Given identical salience the decode is bit-equal to numpy: argmax index, float64 9-bin local average
+    (rmvpe.py:385-409).  f0 = 10 * 2^(cents/1200) may differ in the last ulp of libm's pow."""
+    rng = np.random.default_rng(1)
+    T = 20000 if dev.big else 500
+    sal = rng.random((T, 360)).astype(np.float32) ** 4
+    sal[3] = 0.01                                     # below threshold -> 0
+    sal[7, :5] = [0.9, 0.9, 0.1, 0.2, 0.3]            # tie: first maximum wins; window clipped at the low edge
+    sal[8, 355:] = [0.1, 0.2, 0.3, 0.95, 0.95]        # window clipped at the high edge
+    cents, f0, center = ops.salience_decode(dev.t(torch.from_numpy(sal)), 0.03, want_center=True)
+    assert np.array_equal(center.cpu().numpy(), sal.argmax(1))
+    assert np.array_equal(cents.cpu().numpy(), orm.to_local_average_cents(sal, 0.03))
+    ref_f0 = orm.decode(sal, 0.03)
+    got = f0.cpu().numpy()
+    assert np.array_equal(got == 0, ref_f0 == 0)
+    assert np.max(np.abs(got - ref_f0) / np.maximum(ref_f0, 1e-9)) < 1e-15
+
+
+def test_f0_coarse_bit_exact(dev):
+    """vc_infer_pipeline.py:346,361-368 incl. round-half-even and the 1 / 255 clamps."""
+    rng = np.random.default_rng(2)
+    f0 = np.concatenate([rng.random(2000) * 1200, np.zeros(50), [49.9, 50.0, 1100.0, 1100.1, 5000.0]])
+    for key in (0, 3, -12):
+        out, coarse = ops.f0_coarse(dev.t(torch.from_numpy(f0)), pow(2, key / 12), 1127 * np.log(1 + 50 / 700),
+                                    1127 * np.log(1 + 1100 / 700))
+        oc, ob = orm.f0_to_coarse(f0, key)
+        assert np.array_equal(coarse.cpu().numpy(), oc)
+        assert np.array_equal(out.cpu().numpy(), ob)
+        assert coarse.min() >= 1 and coarse.max() <= 255
+
+
+@pytest.mark.gpu
+def test_rmvpe_full_matches_oracle():
+    """Full-size RMVPE (90 M parameters) on 3 s of audio vs the oracle on the host CPU."""
+    import conftest
+    conftest._bind("hip")
+    sd = weights.rmvpe_state_dict(weights.RMVPE_FULL, 1234)
+    r = RMVPE(None, False, "cuda:0", state_dict=sd)
+    audio = vocal_like(3.0, 16000, seed=9)
+    of0, ohid = orm.infer_from_audio(sd, audio, 0.03)
+    mel = r.mel_extractor(torch.from_numpy(audio)[None])
+    hid = r.mel2hidden(mel)[0].cpu().numpy()
+    assert np.abs(hid - ohid).max() < 1e-3
+    agree = hid.argmax(1) == ohid.argmax(1)
+    assert agree.mean() > 0.98, "salience argmax agreement %.3f" % agree.mean()
+    f0 = r.infer_from_audio(audio, 0.03)
+    assert np.abs(f0 - of0)[agree].max() / max(1.0, of0.max()) < 1e-3

@@ -7,8 +7,10 @@ import pytest
 import torch
 
 from conftest import rel_rms
+from oracle import hubert as ohub
+from oracle import rmvpe as orm
 from oracle import synth, weights
-from oracle.inputs import synth_inputs
+from oracle.inputs import synth_inputs, vocal_like
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
@@ -24,3 +26,46 @@ def test_oracle_synth_matches_reference_golden(name, cfg, T):
     assert rel_rms(m_p[0], torch.from_numpy(gold["m_p"])) < 1e-5
     assert rel_rms(z[0], torch.from_numpy(gold["z"])) < 1e-5
     assert rel_rms(o[0, 0], torch.from_numpy(gold["audio"])) < 1e-5
+
+
+@pytest.mark.parametrize("name,cfg", [("hubert_tiny_1s", weights.HUBERT_TINY), ("hubert_base_1s", weights.HUBERT_BASE)])
+def test_oracle_hubert_matches_transformers_golden(name, cfg):
+    """fairseq is not installable here; the HuBERT restatement is pinned against transformers.HubertModel."""
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    seed = int(gold["seed"][0])
+    sd = weights.hubert_state_dict(cfg, seed)
+    wav = torch.from_numpy(vocal_like(float(gold["seconds"][0]), 16000, seed + 2)).unsqueeze(0)
+    with torch.no_grad():
+        y = ohub.extract_features(sd, cfg, wav, cfg["layers"])
+        y9 = ohub.extract_features(sd, cfg, wav, min(9, cfg["layers"]))
+    assert rel_rms(y[0], torch.from_numpy(gold["last"])) < 1e-5
+    assert rel_rms(y9[0], torch.from_numpy(gold["layer9"])) < 1e-5
+
+
+@pytest.mark.parametrize("name,cfg", [("rmvpe_tiny_1s", weights.RMVPE_TINY), ("rmvpe_full_1s", weights.RMVPE_FULL)])
+def test_oracle_rmvpe_matches_reference_golden(name, cfg):
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    seed = int(gold["seed"][0])
+    sd = weights.rmvpe_state_dict(cfg, seed)
+    audio = vocal_like(float(gold["seconds"][0]), 16000, seed + 3)
+    f0, hidden = orm.infer_from_audio(sd, audio, 0.03)
+    assert np.abs(hidden - gold["hidden"].astype(np.float32)).max() < 2e-3   # fixture stored as fp16
+    assert np.array_equal(hidden.argmax(1), gold["argmax"])
+    assert np.allclose(f0, gold["f0"], rtol=1e-6, atol=1e-6)
+    omel = orm.log_mel(torch.from_numpy(audio)[None], torch.from_numpy(orm.mel_filterbank()))
+    assert (omel[0] - torch.from_numpy(gold["mel"])).abs().max() < 1e-4
+
+
+def test_oracle_decode_matches_reference_loop():
+    """to_local_average_cents restated vectorised vs the reference's per-frame Python loop semantics
+    (window of 9 around the argmax on the zero-padded salience, rmvpe.py:385-409)."""
+    rng = np.random.default_rng(0)
+    sal = rng.random((64, 360)).astype(np.float32) ** 3
+    cm = np.pad(20 * np.arange(360) + 1997.3794084376191, (4, 4))
+    sp = np.pad(sal, ((0, 0), (4, 4)))
+    want = []
+    for i in range(sal.shape[0]):
+        c = int(np.argmax(sal[i])) + 4
+        s9, m9 = sp[i, c - 4:c + 5], cm[c - 4:c + 5]
+        want.append(np.sum(s9 * m9) / np.sum(s9) if sp[i].max() > 0.05 else 0.0)
+    assert np.allclose(orm.to_local_average_cents(sal, 0.05), np.array(want), rtol=1e-12)
