@@ -222,3 +222,35 @@ extern "C" int aicg_feats_prepare(const float* feats, const float* feats0, const
                        protect);
     return check_launch("feats_prepare_kernel");
 }
+
+namespace aicg {
+__global__ void __launch_bounds__(256) mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = a[i] * b[i];
+}
+__global__ void __launch_bounds__(256) axpbypcz_kernel(const float* __restrict__ a, float alpha, const float* __restrict__ b,
+                                                       float beta, const float* __restrict__ c, float gamma,
+                                                       float* __restrict__ out, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float v = alpha * a[i];
+        if (b) v += beta * b[i];
+        if (c) v += gamma * c[i];
+        out[i] = v;
+    }
+}
+}  // namespace aicg
+
+extern "C" int aicg_mul(const float* a, const float* b, float* out, int64_t n, void* stream) {
+    if (!a || !b || !out) return aicg::fail(AICG_E_ARG, "aicg_mul: null pointer");
+    if (n == 0) return AICG_OK;
+    hipLaunchKernelGGL(aicg::mul_kernel, dim3(aicg::ew_grid(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, (long)n);
+    return aicg::check_launch("mul_kernel");
+}
+
+extern "C" int aicg_axpbypcz(const float* a, float alpha, const float* b, float beta, const float* c, float gamma, float* out,
+                             int64_t n, void* stream) {
+    if (!a || !out) return aicg::fail(AICG_E_ARG, "aicg_axpbypcz: null pointer");
+    if (n == 0) return AICG_OK;
+    hipLaunchKernelGGL(aicg::axpbypcz_kernel, dim3(aicg::ew_grid(n)), dim3(256), 0, (hipStream_t)stream, a, alpha, b, beta, c,
+                       gamma, out, (long)n);
+    return aicg::check_launch("axpbypcz_kernel");
+}

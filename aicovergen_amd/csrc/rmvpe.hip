@@ -98,6 +98,7 @@ __global__ void __launch_bounds__(256) salience_decode_kernel(const float* __res
         if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
     }
     if (lane == 0) {
+#pragma clang fp contract(off)  // numpy rounds every product and sum separately: no fma fusion here
         // np.sum(todo_salience * todo_cents_mapping, 1) is float64 (fp32 x fp64 products); np.sum(todo_salience, 1)
         // stays float32; the division promotes the fp32 weight sum to float64.
         double prod[9];
@@ -126,6 +127,7 @@ __global__ void __launch_bounds__(256) salience_decode_kernel(const float* __res
 __global__ void __launch_bounds__(256) f0_coarse_kernel(const double* __restrict__ f0_in, double factor, double* __restrict__ f0_out,
                                                         long* __restrict__ coarse, long n, double mel_min, double mel_max) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+#pragma clang fp contract(off)  // bit-exact with numpy's separately rounded float64 ops
         const double f = f0_in[i] * factor;
         f0_out[i] = f;
         double mel = 1127.0 * log(1.0 + f / 700.0);

@@ -199,12 +199,11 @@ class _SynthesizerBase:
         return P
 
     # ---- forward pieces -----------------------------------------------------------------------------------
-    def _enc_p(self, P, phone, pitch):
+    def _enc_p(self, P, phone_ct, pitch):
         """TextEncoder{256,768}.forward + attentions.Encoder.forward (models.py:93-108, attentions.py:61-73)."""
         C, H = self.hidden_channels, self.n_heads
         dk = C // H
-        T = phone.shape[1]
-        phone_ct = phone[0].t().contiguous().unsqueeze(0)  # (1, phone_dim, T)  layout plumbing
+        T = phone_ct.shape[2]
         res = None
         if pitch is not None:
             res = P["emb_pitch"][pitch[0]].t().contiguous().unsqueeze(0)  # embedding gather (1, C, T)
@@ -300,18 +299,24 @@ class _SynthesizerBase:
         # F.leaky_relu default slope 0.01 (models.py:513), conv_post (no bias), tanh
         return ops.conv(x, P["conv_post"], pre_act=ops.ACT_LRELU, pre_slope=0.01, act=ops.ACT_TANH)
 
-    def infer(self, phone, phone_lengths, pitch=None, nsff0=None, sid=None, max_len=None, noise_z=None, noise_src=None):
+    def infer(self, phone, phone_lengths, pitch=None, nsff0=None, sid=None, max_len=None, noise_z=None, noise_src=None,
+              phone_ct=None):
         """Same contract as the reference (models.py:745-751).  `noise_z` (1, inter, T) and `noise_src` (T*upp)
-        optionally replace the two torch.randn_like draws (parity tests inject them on both sides)."""
+        optionally replace the two torch.randn_like draws (parity tests inject them on both sides).  `phone_ct`
+        (1, phone_dim, T) passes the features already channel-major (what aicg_feats_prepare writes)."""
         if not self.use_f0 and sid is None:  # _nono signature: infer(phone, phone_lengths, sid, max_len=None)
             sid, pitch = pitch, None
         P = self._prepare()
         dev = self.device
-        phone = phone.to(dev).float()
-        assert phone.shape[0] == 1, "batch 1 (the reference pipeline never batches chunks)"
-        T = phone.shape[1]
+        if phone_ct is None:
+            phone = phone.to(dev).float()
+            assert phone.shape[0] == 1, "batch 1 (the reference pipeline never batches chunks)"
+            T = phone.shape[1]
+            phone_ct = phone[0].t().contiguous().unsqueeze(0)  # (1, phone_dim, T)  layout plumbing
+        else:
+            T = phone_ct.shape[2]
         g = P["emb_g"][sid.to(dev).reshape(-1)[:1]].unsqueeze(-1).contiguous()  # (1, gin, 1)
-        stats = self._enc_p(P, phone, None if pitch is None else pitch.to(dev))
+        stats = self._enc_p(P, phone_ct, None if pitch is None else pitch.to(dev))
         if noise_z is None:
             noise_z = torch.randn((1, self.inter_channels, T), device=dev)  # reference: models.py:748
         z_p = ops.prior_sample(stats, noise_z.to(dev).float().contiguous(), 0.66666)

@@ -437,3 +437,42 @@ def f0_coarse(f0, factor, mel_min, mel_max):
     _lib.call("aicg_f0_coarse", _ptr(f0), float(factor), _ptr(out), _ptr(coarse), f0.numel(), float(mel_min), float(mel_max),
               _stream(f0))
     return out, coarse
+
+
+# ---------------------------------------------------------------------------------------------------
+# MDX-Net helpers
+# ---------------------------------------------------------------------------------------------------
+def linear_last(x, weight, bias=None, ch_scale=None, ch_shift=None, act=ACT_NONE, res=None, out=None):
+    """nn.Linear over the last axis of a contiguous (B, C, T, F) map (+ per-channel affine, act, residual)."""
+    assert x.is_contiguous() and x.dim() == 4 and weight.is_contiguous()
+    b, c, t, f = x.shape
+    o = weight.shape[0]
+    assert weight.shape[1] == f
+    if out is None:
+        out = torch.empty((b, c, t, o), dtype=torch.float32, device=x.device)
+    if res is not None:
+        assert res.is_contiguous() and res.shape == out.shape
+    _check(x, weight, bias, ch_scale, ch_shift, res, out)
+    _lib.call("aicg_gemm_nt", _ptr(x), _ptr(weight), _ptr(bias), _ptr(ch_scale), _ptr(ch_shift), _ptr(res), _ptr(out),
+              b * c * t, f, o, f, f, o, o, t, c, act, _stream(x))
+    return out
+
+
+def mul(a, b, out=None):
+    assert a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
+    if out is None:
+        out = torch.empty_like(a)
+    _check(a, b, out)
+    _lib.call("aicg_mul", _ptr(a), _ptr(b), _ptr(out), a.numel(), _stream(a))
+    return out
+
+
+def axpbypcz(a, alpha, b=None, beta=0.0, c=None, gamma=0.0, out=None):
+    """out = alpha*a + beta*b + gamma*c over contiguous fp32 tensors of one shape."""
+    assert a.is_contiguous() and (b is None or b.is_contiguous()) and (c is None or c.is_contiguous())
+    if out is None:
+        out = torch.empty_like(a)
+    _check(a, b, c, out)
+    _lib.call("aicg_axpbypcz", _ptr(a), float(alpha), _ptr(b), float(beta), _ptr(c), float(gamma), _ptr(out), a.numel(),
+              _stream(a))
+    return out

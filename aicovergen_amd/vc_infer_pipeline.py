@@ -1,0 +1,255 @@
+"""RVC voice-conversion pipeline on the gfx950 kernels behind the reference's `VC` class
+(reference src/vc_infer_pipeline.py:63-653; `Pipeline` is the name upstream RVC uses and BASELINE.json quotes).
+
+Kept exactly: chunk geometry from Config (x_pad, x_query, x_center, x_max), the 48 Hz zero-phase high-pass, the
+quietest-sample cut search, reflect padding, whole-track f0, per-chunk vc(), RMS mixing, peak limiting and the
+truncating int16 conversion, the in-place `times = [hubert, f0, synth]` accounting.
+Moved to the device: HuBERT, RMVPE (incl. the salience decode and the coarse-pitch quantiser), the feature
+upsample / protect blend and the whole synthesizer.  Host numpy keeps the O(N) pre/post steps.
+"""
+import os
+import traceback
+from time import time as ttime
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from scipy import signal
+
+from . import ops
+from . import dist as adist
+
+BASE_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+bh, ah = signal.butter(N=5, Wn=48, btype="high", fs=16000)  # reference :22
+
+input_audio_path2wav = {}
+
+
+def _rms_frames(y, frame_length, hop_length):
+    """librosa.feature.rms(y=y, frame_length=, hop_length=) of librosa 0.9.1: center=True with reflect padding,
+    frame power mean, sqrt; returns (1, n_frames) float32 like librosa does for float32 input."""
+    y = np.asarray(y)
+    pad = frame_length // 2
+    yp = np.pad(y, (pad, pad), mode="reflect")
+    n_frames = 1 + (len(yp) - frame_length) // hop_length
+    idx = np.arange(frame_length)[None, :] + hop_length * np.arange(n_frames)[:, None]
+    power = np.mean(np.abs(yp[idx]) ** 2, axis=1)
+    return np.sqrt(power)[None, :].astype(y.dtype if y.dtype in (np.float32, np.float64) else np.float32)
+
+
+def change_rms(data1, sr1, data2, sr2, rate):
+    """RMS-envelope mix of input (1) into output (2) (reference :41-60)."""
+    rms1 = _rms_frames(data1, sr1 // 2 * 2, sr1 // 2)
+    rms2 = _rms_frames(data2, sr2 // 2 * 2, sr2 // 2)
+    rms1 = F.interpolate(torch.from_numpy(rms1).unsqueeze(0), size=data2.shape[0], mode="linear").squeeze()
+    rms2 = F.interpolate(torch.from_numpy(rms2).unsqueeze(0), size=data2.shape[0], mode="linear").squeeze()
+    rms2 = torch.max(rms2, torch.zeros_like(rms2) + 1e-6)
+    data2 *= (torch.pow(rms1, torch.tensor(1 - rate)) * torch.pow(rms2, torch.tensor(rate - 1))).numpy()
+    return data2
+
+
+class VC(object):
+    def __init__(self, tgt_sr, config):
+        self.x_pad, self.x_query, self.x_center, self.x_max, self.is_half = (
+            config.x_pad, config.x_query, config.x_center, config.x_max, config.is_half)
+        self.sr = 16000      # HuBERT input rate
+        self.window = 160    # samples per f0 frame
+        self.t_pad = self.sr * self.x_pad
+        self.t_pad_tgt = tgt_sr * self.x_pad
+        self.t_pad2 = self.t_pad * 2
+        self.t_query = self.sr * self.x_query
+        self.t_center = self.sr * self.x_center
+        self.t_max = self.sr * self.x_max
+        self.device = config.device
+        self.rmvpe_path = os.path.join(BASE_DIR, 'rvc_models', 'rmvpe.pt')
+
+    def get_optimal_torch_device(self, index: int = 0) -> torch.device:
+        if torch.cuda.is_available():
+            return torch.device(f"cuda:{index % torch.cuda.device_count()}")
+        return torch.device("cpu")
+
+    # ---- f0 ---------------------------------------------------------------------------------------------------
+    def get_f0_crepe_computation(self, x, f0_min, f0_max, p_len, hop_length=160, model="full"):
+        from . import crepe
+        return crepe.mangio_crepe_f0(self, x, f0_min, f0_max, p_len, hop_length, model)
+
+    def get_f0(self, input_audio_path, x, p_len, f0_up_key, f0_method, filter_radius, crepe_hop_length, inp_f0=None):
+        """-> (f0_coarse int64 (n,), f0 float64 (n,)) (reference :262-370)."""
+        f0_min, f0_max = 50, 1100
+        f0_mel_min = 1127 * np.log(1 + f0_min / 700)
+        f0_mel_max = 1127 * np.log(1 + f0_max / 700)
+        if f0_method == "rmvpe":
+            if not hasattr(self, "model_rmvpe"):
+                from .rmvpe import RMVPE
+                self.model_rmvpe = RMVPE(self.rmvpe_path, is_half=self.is_half, device=self.device)
+            f0 = self.model_rmvpe.infer_from_audio(x, thred=0.03)
+        elif f0_method in ("mangio-crepe", "mangio-crepe-tiny"):
+            f0 = self.get_f0_crepe_computation(x, f0_min, f0_max, p_len, crepe_hop_length,
+                                               "tiny" if f0_method.endswith("tiny") else "full")
+        else:
+            raise NotImplementedError(
+                "f0_method %r needs parselmouth / pyworld / torchcrepe filters, which are outside the MI355X hot path "
+                "(supported: rmvpe, mangio-crepe)" % f0_method)
+        tf0 = self.sr // self.window
+        f0 = np.asarray(f0, dtype=np.float64)
+        factor = pow(2, f0_up_key / 12)
+        if inp_f0 is not None:
+            f0 = f0 * factor
+            factor = 1.0
+            delta_t = np.round((inp_f0[:, 0].max() - inp_f0[:, 0].min()) * tf0 + 1).astype("int16")
+            replace_f0 = np.interp(list(range(delta_t)), inp_f0[:, 0] * 100, inp_f0[:, 1])
+            shape = f0[self.x_pad * tf0: self.x_pad * tf0 + len(replace_f0)].shape[0]
+            f0[self.x_pad * tf0: self.x_pad * tf0 + len(replace_f0)] = replace_f0[:shape]
+        dev = self.device if str(self.device) != "cpu" or ops._lib.backend() == "emu" else self.device
+        f0bak, coarse = ops.f0_coarse(torch.from_numpy(f0).to(dev), factor, f0_mel_min, f0_mel_max)
+        return coarse.cpu().numpy(), f0bak.cpu().numpy()
+
+    # ---- one chunk ----------------------------------------------------------------------------------------------
+    def vc(self, model, net_g, sid, audio0, pitch, pitchf, times, index, big_npy, index_rate, version, protect,
+           noise=None):
+        """One padded chunk -> float32 waveform at tgt_sr (reference :372-472).  `noise` = (noise_z, noise_src)
+        replaces the synthesizer's random draws (parity tests)."""
+        feats = torch.from_numpy(np.ascontiguousarray(audio0)).float()
+        if feats.dim() == 2:
+            feats = feats.mean(-1)
+        assert feats.dim() == 1, feats.dim()
+        feats = feats.view(1, -1)
+        padding_mask = torch.zeros(feats.shape, dtype=torch.bool)
+        t0 = ttime()
+        logits = model.extract_features(source=feats.to(self.device), padding_mask=padding_mask,
+                                        output_layer=9 if version == "v1" else 12)
+        feats = model.final_proj(logits[0]) if version == "v1" else logits[0]
+        use_protect = protect < 0.5 and pitch is not None and pitchf is not None
+        feats0 = feats.clone() if use_protect else None
+        if index is not None and big_npy is not None and index_rate != 0:
+            npy = feats[0].cpu().numpy().astype("float32")
+            score, ix = index.search(npy, k=8)
+            weight = np.square(1 / score)
+            weight /= weight.sum(axis=1, keepdims=True)
+            npy = np.sum(big_npy[ix] * np.expand_dims(weight, axis=2), axis=1)
+            feats = torch.from_numpy(npy.astype("float32")).unsqueeze(0).to(self.device) * index_rate + (1 - index_rate) * feats
+        if self._sync():
+            torch.cuda.synchronize()
+        t1 = ttime()
+        p_len = audio0.shape[0] // self.window
+        if 2 * feats.shape[1] < p_len:
+            p_len = 2 * feats.shape[1]
+        if pitch is not None and pitchf is not None:
+            pitch = pitch[:, :p_len]
+            pitchf = pitchf[:, :p_len]
+        # nearest x2 upsample + protect blend, written channel-major for the synthesizer (:433-452)
+        phone_ct = ops.feats_prepare(feats[0], p_len, feats0[0] if use_protect else None,
+                                     pitchf[0].float() if use_protect else None, protect)
+        nz, ns = noise if noise is not None else (None, None)
+        lens = torch.tensor([p_len], device=self.device).long()
+        if pitch is not None and pitchf is not None:
+            o = net_g.infer(None, lens, pitch, pitchf, sid, noise_z=nz, noise_src=ns, phone_ct=phone_ct)[0]
+        else:
+            o = net_g.infer(None, lens, sid, noise_z=nz, noise_src=ns, phone_ct=phone_ct)[0]
+        audio1 = o[0, 0].data.cpu().float().numpy()
+        t2 = ttime()
+        times[0] += t1 - t0
+        times[2] += t2 - t1
+        return audio1
+
+    def _sync(self):
+        return torch.cuda.is_available() and str(self.device).startswith("cuda")
+
+    # ---- whole track ----------------------------------------------------------------------------------------------
+    def plan(self, audio):
+        """High-pass, cut search and padding (reference :513-534): -> (audio_hp float64, audio_pad, opt_ts, p_len)."""
+        audio = signal.filtfilt(bh, ah, audio)
+        audio_pad = np.pad(audio, (self.window // 2, self.window // 2), mode="reflect")
+        opt_ts = []
+        if audio_pad.shape[0] > self.t_max:
+            audio_sum = np.zeros_like(audio)
+            for i in range(self.window):
+                audio_sum += audio_pad[i: i - self.window]
+            for t in range(self.t_center, audio.shape[0], self.t_center):
+                seg = np.abs(audio_sum[t - self.t_query: t + self.t_query])
+                opt_ts.append(t - self.t_query + np.where(seg == seg.min())[0][0])
+        audio_pad = np.pad(audio, (self.t_pad, self.t_pad), mode="reflect")
+        return audio, audio_pad, opt_ts, audio_pad.shape[0] // self.window
+
+    def chunk_bounds(self, audio_pad, opt_ts):
+        """[(start, end)] sample ranges of audio_pad handed to vc(), in order (reference :567-637)."""
+        bounds = []
+        s = 0
+        t = None
+        for t in opt_ts:
+            t = t // self.window * self.window
+            bounds.append((s, t + self.t_pad2 + self.window))
+            s = t
+        bounds.append((t if t is not None else 0, audio_pad.shape[0]))
+        return bounds
+
+    def pipeline(self, model, net_g, sid, audio, input_audio_path, times, f0_up_key, f0_method, file_index, index_rate,
+                 if_f0, filter_radius, tgt_sr, resample_sr, rms_mix_rate, version, protect, crepe_hop_length, f0_file=None,
+                 noise_fn=None, group=None):
+        """Same contract as the reference (:474-653): float32 16 kHz mono in, int16 at tgt_sr out.
+        `noise_fn(chunk_index, T) -> (noise_z, noise_src)` injects the synthesizer noise (tests); `group` shards the
+        chunk loop over the ranks of a torch.distributed process group."""
+        index = big_npy = None
+        if file_index != "" and os.path.exists(file_index) and index_rate != 0:
+            try:
+                import faiss
+                index = faiss.read_index(file_index)
+                big_npy = index.reconstruct_n(0, index.ntotal)
+            except Exception:
+                traceback.print_exc()
+                index = big_npy = None
+        audio, audio_pad, opt_ts, p_len = self.plan(audio)
+        t1 = ttime()
+        inp_f0 = None
+        if hasattr(f0_file, "name"):
+            try:
+                with open(f0_file.name, "r") as f:
+                    lines = f.read().strip("\n").split("\n")
+                inp_f0 = np.array([[float(i) for i in line.split(",")] for line in lines], dtype="float32")
+            except Exception:
+                traceback.print_exc()
+        sid = torch.tensor(sid, device=self.device).unsqueeze(0).long()
+        pitch, pitchf = None, None
+        if if_f0 == 1:
+            pitch, pitchf = self.get_f0(input_audio_path, audio_pad, p_len, f0_up_key, f0_method, filter_radius,
+                                        crepe_hop_length, inp_f0)
+            pitch = torch.tensor(pitch[:p_len], device=self.device).unsqueeze(0).long()
+            pitchf = torch.tensor(pitchf[:p_len], device=self.device).unsqueeze(0).float()
+        if self._sync():
+            torch.cuda.synchronize()
+        t2 = ttime()
+        times[1] += t2 - t1
+        bounds = self.chunk_bounds(audio_pad, opt_ts)
+        rank, world = adist.world(group)
+        pieces = {}
+        for ci, (s, e) in enumerate(bounds):
+            if ci % world != rank:
+                continue
+            last = ci == len(bounds) - 1
+            if if_f0 == 1:
+                pe = None if last else (e - self.window) // self.window
+                pc, pcf = pitch[:, s // self.window: pe], pitchf[:, s // self.window: pe]
+            else:
+                pc = pcf = None
+            noise = noise_fn(ci, s, e) if noise_fn is not None else None
+            out = self.vc(model, net_g, sid, audio_pad[s:e], pc, pcf, times, index, big_npy, index_rate, version, protect,
+                          noise=noise)
+            pieces[ci] = out[self.t_pad_tgt: -self.t_pad_tgt]
+        pieces = adist.gather_pieces(pieces, len(bounds), self.device, group)
+        audio_opt = np.concatenate([pieces[i] for i in range(len(bounds))])
+        if rms_mix_rate != 1:
+            audio_opt = change_rms(audio, 16000, audio_opt, tgt_sr, rms_mix_rate)
+        if resample_sr >= 16000 and tgt_sr != resample_sr:
+            from scipy.signal import resample_poly
+            g = np.gcd(int(tgt_sr), int(resample_sr))
+            audio_opt = resample_poly(audio_opt, resample_sr // g, tgt_sr // g).astype(np.float32)
+        audio_max = np.abs(audio_opt).max() / 0.99
+        max_int16 = 32768
+        if audio_max > 1:
+            max_int16 /= audio_max
+        audio_opt = (audio_opt * max_int16).astype(np.int16)
+        return audio_opt
+
+
+Pipeline = VC  # the name BASELINE.json / upstream RVC use for this class

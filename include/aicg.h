@@ -183,6 +183,22 @@ int aicg_salience_decode(const float* salience, double* cents, double* f0, int* 
 int aicg_f0_coarse(const double* f0_in, double factor, double* f0_out, int64_t* coarse, int64_t n, double mel_min,
                    double mel_max, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * MDX-Net separator helpers.  The reference runs the network as an opaque ONNX graph (src/mdx.py:74-77,193);
+ * its layers map onto aicg_conv_forward / aicg_col2im plus the last-axis Linear below.
+ * ---------------------------------------------------------------------------------------------- */
+/* c[r][o] = act((sum_i a[r][i] w[o][i] + bias[o]) * row_scale[ch(r)] + row_shift[ch(r)]) + res[r][o],
+ * ch(r) = (r / rows_per_ch) % n_ch.  nn.Linear over the last (frequency) axis of a (B,C,T,F) map followed by
+ * eval-mode BatchNorm2d(C) + ReLU (the TDF block), with the TFC_TDF residual add fused. */
+int aicg_gemm_nt(const float* a, const float* w, const float* bias, const float* row_scale,
+                 const float* row_shift, const float* res, float* c, int64_t R, int K, int O, int64_t lda,
+                 int64_t ldw, int64_t ldc, int64_t ldr, int rows_per_ch, int n_ch, int act, void* stream);
+/* out = a * b elementwise (U-Net skip connection of the TFC-TDF net: x *= ds_outputs[-i-1]) */
+int aicg_mul(const float* a, const float* b, float* out, int64_t n, void* stream);
+/* run_mdx epilogue pieces (src/mdx.py:259-267,280): out = alpha * a + beta * b (+ gamma * c if c) */
+int aicg_axpbypcz(const float* a, float alpha, const float* b, float beta, const float* c, float gamma, float* out,
+                  int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -224,3 +224,79 @@ def rmvpe_state_dict(cfg=RMVPE_FULL, seed=1234):
     sd["fc.1.weight"] = g.normal(360, 512, std=3.0 / math.sqrt(512))
     sd["fc.1.bias"] = g.normal(360, std=0.5) - 2.0
     return {k: (v.contiguous().float() if v.is_floating_point() else v) for k, v in sd.items()}
+
+
+# ---------------------------------------------------------------------------------------------------
+# MDX-Net (TFC-TDF U-Net, "ConvTDFNet" of kuielab/mdx-net as shipped in the UVR-MDX-NET .onnx files).
+# The reference only downloads the graphs (src/download_models.py:4,21) and runs them with onnxruntime
+# (src/mdx.py:74-77): architecture recalled from the published kuielab code, PARITY UNPINNED (no .onnx offline).
+# ---------------------------------------------------------------------------------------------------
+MDX_VOC_FT = dict(dim_c=4, g=48, n=5, l=3, k=3, bn=8, dim_f=3072, dim_t=256, n_fft=7680)   # model_data.json Voc_FT class
+MDX_TINY = dict(dim_c=4, g=8, n=2, l=2, k=3, bn=4, dim_f=64, dim_t=16, n_fft=160)
+
+
+def _bn2(sd, g, name, c):
+    _bn(sd, g, name, c)
+
+
+def _tfc_tdf(sd, g, name, c, l, f, k, bn):
+    for j in range(l):
+        sd["%s.tfc.H.%d.0.weight" % (name, j)] = g.normal(c, c, k, k, std=math.sqrt(2.0 / (c * k * k)))
+        sd["%s.tfc.H.%d.0.bias" % (name, j)] = g.normal(c, std=0.05)
+        _bn2(sd, g, "%s.tfc.H.%d.1" % (name, j), c)
+    sd[name + ".tdf.0.weight"] = g.normal(f // bn, f, std=math.sqrt(2.0 / f))
+    sd[name + ".tdf.0.bias"] = g.normal(f // bn, std=0.05)
+    _bn2(sd, g, name + ".tdf.1", c)
+    sd[name + ".tdf.3.weight"] = g.normal(f, f // bn, std=0.5 * math.sqrt(2.0 / (f // bn)))
+    sd[name + ".tdf.3.bias"] = g.normal(f, std=0.05)
+    _bn2(sd, g, name + ".tdf.4", c)
+
+
+def mdx_state_dict(cfg=MDX_VOC_FT, seed=1234):
+    g = _Gen(seed)
+    sd = {}
+    gg, n, l, k, bn, f = cfg["g"], cfg["n"], cfg["l"], cfg["k"], cfg["bn"], cfg["dim_f"]
+    sd["first_conv.0.weight"] = g.normal(gg, cfg["dim_c"], 1, 1, std=1.0)
+    sd["first_conv.0.bias"] = g.normal(gg, std=0.05)
+    _bn2(sd, g, "first_conv.1", gg)
+    c = gg
+    for i in range(n):
+        _tfc_tdf(sd, g, "ds_dense.%d" % i, c, l, f, k, bn)
+        sd["ds.%d.0.weight" % i] = g.normal(c + gg, c, 2, 2, std=math.sqrt(2.0 / (c * 4)))
+        sd["ds.%d.0.bias" % i] = g.normal(c + gg, std=0.05)
+        _bn2(sd, g, "ds.%d.1" % i, c + gg)
+        f //= 2
+        c += gg
+    _tfc_tdf(sd, g, "mid_dense", c, l, f, k, bn)
+    for i in range(n):
+        sd["us.%d.0.weight" % i] = g.normal(c, c - gg, 2, 2, std=math.sqrt(2.0 / c))
+        sd["us.%d.0.bias" % i] = g.normal(c - gg, std=0.05)
+        _bn2(sd, g, "us.%d.1" % i, c - gg)
+        f *= 2
+        c -= gg
+        _tfc_tdf(sd, g, "us_dense.%d" % i, c, l, f, k, bn)
+    sd["final_conv.0.weight"] = g.normal(cfg["dim_c"], c, 1, 1, std=0.5 / math.sqrt(c))
+    sd["final_conv.0.bias"] = g.normal(cfg["dim_c"], std=0.01)
+    return {kk: (v.contiguous().float() if v.is_floating_point() else v) for kk, v in sd.items()}
+
+
+# ---------------------------------------------------------------------------------------------------
+# small end-to-end model set (CPU-side pipeline tests): 768-d HuBERT so the reference's TextEncoder768 accepts it,
+# and a synthesizer that upsamples only 16x (tgt_sr 1600) so the emulator finishes in seconds
+# ---------------------------------------------------------------------------------------------------
+HUBERT_SMALL768 = dict(conv_dim=32, conv_kernel=(10, 3, 3, 3, 3, 2, 2), conv_stride=(5, 2, 2, 2, 2, 2, 2), embed=768,
+                       heads=12, ffn=128, layers=1, pos_k=128, pos_groups=16, final_dim=256)
+SYNTH_CFG_MICRO = [1025, 32, 64, 64, 128, 2, 1, 3, 0, "1", [3, 7, 11], [[1, 3, 5], [1, 3, 5], [1, 3, 5]],
+                   [2, 2, 2, 2], 64, [4, 4, 4, 4], 4, 32, 1600]
+
+
+def small_model_set(seed=1234):
+    return dict(hubert_cfg=HUBERT_SMALL768, hubert_sd=hubert_state_dict(HUBERT_SMALL768, seed),
+                rmvpe_sd=rmvpe_state_dict(RMVPE_TINY, seed + 1),
+                synth_cfg=SYNTH_CFG_MICRO, synth_sd=synth_state_dict(SYNTH_CFG_MICRO, seed + 2))
+
+
+def full_model_set(seed=1234):
+    return dict(hubert_cfg=HUBERT_BASE, hubert_sd=hubert_state_dict(HUBERT_BASE, seed),
+                rmvpe_sd=rmvpe_state_dict(RMVPE_FULL, seed + 1),
+                synth_cfg=SYNTH_CFG_40K_V2, synth_sd=synth_state_dict(SYNTH_CFG_40K_V2, seed + 2))

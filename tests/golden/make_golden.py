@@ -108,6 +108,78 @@ def make_rmvpe(name, cfg, seconds, seed):
     print(name, hidden.shape, float((f0 > 0).mean()))
 
 
+def make_pipeline(name, seconds, seed):
+    """End to end: the reference's own VC.pipeline (src/vc_infer_pipeline.py) + its synthesizer + its RMVPE, with
+    the seeded small model set; HuBERT (fairseq, absent) is served by the oracle restatement (itself pinned to
+    transformers.HubertModel).  Missing third-party modules are stubbed exactly as SURVEY 8(c) describes."""
+    import types
+    import transformers  # noqa: F401  (must be imported before librosa is stubbed, SURVEY appendix A)
+    from oracle import hubert as ohub
+    from oracle import pipeline as opipe
+    from oracle import rmvpe as orm
+    from oracle import weights
+    from oracle.inputs import vocal_like
+    np.int = int  # removed alias used at vc_infer_pipeline.py:368
+    for mod in ("faiss", "parselmouth", "pyworld", "torchcrepe"):
+        sys.modules.setdefault(mod, types.ModuleType(mod))
+    lib = types.ModuleType("librosa")
+    lib.filters = types.ModuleType("librosa.filters")
+    lib.feature = types.ModuleType("librosa.feature")
+    lib.filters.mel = lambda sr, n_fft, n_mels, fmin, fmax, htk: orm.mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
+    lib.feature.rms = lambda y, frame_length, hop_length: opipe.rms_frames(y, frame_length, hop_length)
+    lib.__spec__ = None
+    sys.modules["librosa"], sys.modules["librosa.filters"], sys.modules["librosa.feature"] = lib, lib.filters, lib.feature
+    sys.path.insert(0, REF)
+    import rmvpe as ref_rmvpe
+    import vc_infer_pipeline as ref_vc
+    from infer_pack.models import SynthesizerTrnMs768NSFsid
+    nets = weights.small_model_set(seed)
+    cfg = nets["synth_cfg"]
+    tgt_sr = cfg[-1]
+
+    class Cfg:
+        x_pad, x_query, x_center, x_max, is_half, device = 1, 1, 1, 2, False, "cpu"
+
+    vc = ref_vc.VC(tgt_sr, Cfg())
+    e2e = ref_rmvpe.E2E(1, 1, (2, 2), 5, 1, 1, 2)
+    e2e.load_state_dict(nets["rmvpe_sd"])
+    e2e.eval()
+    r = ref_rmvpe.RMVPE.__new__(ref_rmvpe.RMVPE)
+    r.model, r.is_half, r.device, r.resample_kernel = e2e, False, "cpu", {}
+    r.mel_extractor = ref_rmvpe.MelSpectrogram(False, 128, 16000, 1024, 160, None, 30, 8000)
+    r.cents_mapping = np.pad(20 * np.arange(360) + 1997.3794084376191, (4, 4))
+    vc.model_rmvpe = r
+    net_g = SynthesizerTrnMs768NSFsid(*cfg, is_half=False)
+    del net_g.enc_q
+    net_g.load_state_dict(nets["synth_sd"], strict=False)
+    net_g.eval()
+
+    class Hub:
+        def extract_features(self, source, padding_mask, output_layer):
+            with torch.no_grad():
+                return (ohub.extract_features(nets["hubert_sd"], nets["hubert_cfg"], source, output_layer), padding_mask)
+
+    upp = int(np.prod(cfg[12]))
+    state = {"calls": 0}
+    orig = torch.randn_like
+
+    def fake_randn_like(x, *a, **k):
+        ci, which = divmod(state["calls"], 2)
+        state["calls"] += 1
+        T = x.shape[2] if which == 0 else x.shape[1] // upp
+        nz, ns = opipe.chunk_noise(ci, T, cfg[2], upp, 7)
+        return nz if which == 0 else ns.unsqueeze(-1)
+
+    audio = vocal_like(seconds, 16000, seed + 5)
+    torch.randn_like = fake_randn_like
+    try:
+        out = vc.pipeline(Hub(), net_g, 0, audio, "x.wav", [0, 0, 0], 0, "rmvpe", "", 0.5, 1, 3, tgt_sr, 0, 0.25, "v2", 0.33, 128)
+    finally:
+        torch.randn_like = orig
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), seed=np.array([seed]), seconds=np.array([seconds]), audio=out)
+    print(name, out.shape, out.dtype, int(np.abs(out).max()))
+
+
 if __name__ == "__main__":
     from oracle import weights
     make_synth("synth_tiny_T24", weights.SYNTH_CFG_TINY, 24, 1234)
@@ -116,3 +188,4 @@ if __name__ == "__main__":
     make_hubert("hubert_base_1s", weights.HUBERT_BASE, 1.0, 1234)
     make_rmvpe("rmvpe_tiny_1s", weights.RMVPE_TINY, 1.0, 1234)
     make_rmvpe("rmvpe_full_1s", weights.RMVPE_FULL, 1.0, 1234)
+    make_pipeline("pipeline_small_2p6s", 2.6, 1234)

@@ -1,0 +1,117 @@
+"""MDX-Net separation path: MDXModel.stft/istft layouts, MDX.segment/pad_wave bookkeeping (bit-exact), the U-Net on
+the HIP kernels and run_mdx's arithmetic vs the oracle restatement of reference src/mdx.py."""
+import numpy as np
+import pytest
+import torch
+
+from aicovergen_amd.mdx import MDX, MDXModel, run_mdx_arrays
+from aicovergen_amd.mdx_net import ConvTDFNet
+from conftest import rel_rms
+from oracle import mdxnet, weights
+from oracle.inputs import song_like
+
+
+def _session(dev, cfg=weights.MDX_TINY, hop=64, seed=1234):
+    sd = weights.mdx_state_dict(cfg, seed)
+    model = MDXModel(dev.device, cfg["dim_f"], cfg["dim_t"], cfg["n_fft"], hop=hop)
+    return sd, model, MDX(None, model, state_dict=sd)
+
+
+def test_unet_matches_oracle(dev):
+    cfg = weights.MDX_TINY
+    sd = weights.mdx_state_dict(cfg, 1234)
+    net = ConvTDFNet(sd, dev.device)
+    for k in ("g", "n", "l", "k", "bn", "dim_f"):
+        assert net.cfg[k] == cfg[k]
+    torch.manual_seed(0)
+    spec = torch.randn(2, 4, cfg["dim_f"], cfg["dim_t"])
+    with torch.no_grad():
+        ref = mdxnet.unet(sd, cfg, spec)
+    assert rel_rms(net(spec), ref) < 1e-4
+
+
+def test_mdxmodel_stft_istft_layouts(dev):
+    cfg = weights.MDX_TINY
+    _, model, _ = _session(dev)
+    torch.manual_seed(1)
+    x = torch.randn(3, 2, model.chunk_size)
+    ref = mdxnet.stft(x, cfg["n_fft"], 64, cfg["dim_f"])
+    assert model.stft(x).shape == ref.shape == (3, 4, cfg["dim_f"], cfg["dim_t"])
+    assert rel_rms(model.stft(x), ref) < 1e-5
+    assert rel_rms(model.istft(ref), mdxnet.istft(ref, cfg["n_fft"], 64)) < 1e-5
+    assert model.n_bins == cfg["n_fft"] // 2 + 1 and model.dim_c == 4
+    assert tuple(model.freq_pad.shape) == (1, 4, model.n_bins - cfg["dim_f"], cfg["dim_t"])
+
+
+def test_segment_and_pad_wave_bookkeeping_bit_exact(dev):
+    """segment(combine=False) -> segment(combine=True) is the identity; pad_wave window count and contents equal
+    the reference's (mdx.py:92-171); a length that is a multiple of gen_size gets a full extra window."""
+    _, model, sess = _session(dev)
+    rng = np.random.default_rng(0)
+    trim = model.n_fft // 2
+    gen = model.chunk_size - 2 * trim
+    for n in (7000, 3 * gen, gen - 1, 1234):
+        wave = rng.standard_normal((2, n)).astype(np.float32)
+        for thr in (1, 2):
+            segs = MDX.segment(wave, False, n // thr, 300)
+            osegs = mdxnet.segment(wave, False, n // thr, 300)
+            assert len(segs) == len(osegs) and all(np.array_equal(a, b) for a, b in zip(segs, osegs))
+            assert np.array_equal(MDX.segment(segs, True, n // thr, 300), wave)
+        mix, pad, tr = sess.pad_wave(wave)
+        omix, opad, otr = mdxnet.pad_wave(wave, model.n_fft, model.chunk_size)
+        assert (pad, tr) == (opad, otr) and mix.shape == omix.shape == ((n + pad) // gen, 2, model.chunk_size)
+        assert torch.equal(mix.cpu(), omix)
+    assert sess.pad_wave(np.zeros((2, 3 * gen), np.float32))[1] == gen
+
+
+def test_process_wave_and_run_mdx_arithmetic(dev):
+    """process_wave (reference semantics, 2 overlapping halves) and the denoise combination
+    0.5 * (-f(-x) + f(x)) (mdx.py:261-263) vs the oracle; also the inverted stem of mdx.py:280."""
+    cfg = weights.MDX_TINY
+    sd, model, sess = _session(dev)
+    wave = song_like(0.2, 44100, seed=3)[:, :7000]
+    wave = wave / np.abs(wave).max()
+    ref = mdxnet.process_wave(sd, cfg, wave, 2, hop=64)
+    got = sess.process_wave(wave, 2)
+    assert got.shape == ref.shape == wave.shape
+    assert np.abs(got - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+    refd = 0.5 * (-mdxnet.process_wave(sd, cfg, -wave, 2, hop=64) + ref)
+    gotd = run_mdx_arrays(sess, wave, True, 2)
+    assert np.abs(gotd - refd).max() < 1e-4 * max(1.0, np.abs(refd).max())
+    assert np.abs(run_mdx_arrays(sess, wave, False, 2) - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+
+
+def test_denoise_is_odd_part(dev):
+    """Size-independent property: the denoise output is the odd part of f, so separate(-x) == -separate(x)."""
+    _, _, sess = _session(dev)
+    wave = song_like(0.1, 44100, seed=5)[:, :3000]
+    a = run_mdx_arrays(sess, wave, True, 2)
+    b = run_mdx_arrays(sess, -wave, True, 2)
+    assert np.abs(a + b).max() < 1e-5 * max(1.0, np.abs(a).max())
+
+
+def test_get_hash_tail(tmp_path):
+    import hashlib
+    p = tmp_path / "m.bin"
+    blob = np.random.default_rng(0).integers(0, 255, 10000 * 1024 + 777, dtype=np.uint8).tobytes()
+    p.write_bytes(blob)
+    assert MDX.get_hash(str(p)) == hashlib.md5(blob[-10000 * 1024:]).hexdigest()
+    p.write_bytes(blob[:1000])
+    assert MDX.get_hash(str(p)) == hashlib.md5(blob[:1000]).hexdigest()
+
+
+@pytest.mark.gpu
+def test_voc_ft_sized_window_matches_oracle():
+    """One full-size window (dim_f 3072, dim_t 256, n_fft 7680: the Voc_FT-class entry of model_data.json) through
+    stft -> U-Net (g=48, 5 levels) -> istft vs the oracle on the host CPU."""
+    import conftest
+    conftest._bind("hip")
+    cfg = weights.MDX_VOC_FT
+    sd = weights.mdx_state_dict(cfg, 1234)
+    model = MDXModel("cuda:0", cfg["dim_f"], cfg["dim_t"], cfg["n_fft"])
+    sess = MDX(None, model, state_dict=sd)
+    x = torch.from_numpy(song_like(model.chunk_size / 44100.0 + 0.01, 44100, seed=2)[:, :model.chunk_size]).unsqueeze(0)
+    with torch.no_grad():
+        ref = mdxnet.istft(mdxnet.unet(sd, cfg, mdxnet.stft(x, cfg["n_fft"], 1024, cfg["dim_f"])), cfg["n_fft"], 1024)
+        got = model.istft_tf(sess.net.forward_tf(model.stft_tf(x.cuda())))
+    assert rel_rms(got, ref) < 1e-4
