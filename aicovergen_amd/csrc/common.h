@@ -26,18 +26,23 @@ __host__ __device__ inline int imax(int a, int b) { return a > b ? a : b; }
 __host__ __device__ inline long lmin(long a, long b) { return a < b ? a : b; }
 __host__ __device__ inline long lmax(long a, long b) { return a > b ? a : b; }
 
-// activations shared by conv epilogues and elementwise kernels (codes: include/aicg.h)
-__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+// activations shared by conv epilogues and elementwise kernels (codes: include/aicg.h).
+// The transcendental ones are kept out of line: the conv kernels instantiate the activation ~80 times per
+// template variant and inlining erff/tanhf there multiplies the code size past the instruction cache.
+__device__ __attribute__((noinline)) inline float apply_act_slow(float v, int act, float slope) {
     switch (act) {
-        case AICG_ACT_NONE: return v;
-        case AICG_ACT_RELU: return v > 0.f ? v : 0.f;
-        case AICG_ACT_LRELU: return v > 0.f ? v : v * slope;
         case AICG_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
         case AICG_ACT_TANH: return tanhf(v);
         case AICG_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
         case AICG_ACT_LOGCLAMP: return logf(fmaxf(v, slope));
         default: return v;
     }
+}
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+    if (act == AICG_ACT_NONE) return v;
+    if (act == AICG_ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == AICG_ACT_LRELU) return v > 0.f ? v : v * slope;
+    return apply_act_slow(v, act, slope);
 }
 
 // block->XCD aware remap (guide T1, bijective form): consecutive logical ids share an XCD's L2.

@@ -9,8 +9,8 @@
 //   * RMVPE and MDX-Net 3x3 Conv2d + folded BatchNorm + ReLU (+ residual) (rmvpe.py:23-58, mdx.py:74-77)
 //
 // GEMM view per group:  M = Cout_g,  N = Ho*Wo (tiled as TH x TW output patches, TW a power of two),
-// K = Cin_g*KH*KW ordered [channel chunk][tap][channel in chunk].
-// A (weights) is pre-packed on the host as [K][Mpad] so a stage is one coalesced float4 copy into LDS;
+// K = Cin_g*KH*KW walked as [channel chunk][tap][channel in chunk].
+// A (weights) is pre-packed on the host as [tap][Cin_pad][Mpad] so a stage is a few coalesced float4 row copies into LDS;
 // B is never materialised: a chunk of BKC input channels of the input patch (with halo) is staged
 // into LDS once -- with the fused pre-activation applied once per element, not once per tap -- and
 // every tap reads it at a shifted offset.  Lane l of a wave feeds the MFMA with
@@ -37,16 +37,23 @@ struct ConvArgs {
     int accumulate;
     int res_first;
     // derived tiling
-    int TW, TWlog2, TH, TH_in, TW_in, TWp, CHS, BKC, TT, tiles_w, tiles_h, nchunk, taps, Mpad, xs_elems;
+    int TW, TWlog2, TH, TH_in, TW_in, TWp, CHS, BKC, BKClog2, TT, tiles_w, tiles_h, nchunk, taps, Mpad, Cin_pad, xs_elems, xs_total;
+    unsigned div_chs, div_twp;  // ceil(2^32 / d) multipliers: idx / d == umulhi(idx, mul) for idx * d < 2^32
     long w_group_stride;
 };
 
-static constexpr int KSTAGE = 32;  // K rows of packed weights staged per barrier pair
+static constexpr int KSTAGE = 64;  // max K rows of packed weights staged per barrier pair
 
-template <int BM, int BN, int WM, int WN>
-__global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs p) {
+// Software pipeline (guide T14, "issue early / write late"):
+//   global loads of stage s+1 (weights, and the input patch when s+1 opens a new channel chunk) are issued into
+//   registers right after the barrier that publishes stage s in LDS, fly under the MFMA loop of stage s, and are
+//   written to LDS after the next barrier.  Inside the MFMA loop the A/B fragments of step i+1 are read from LDS
+//   before the MFMAs of step i issue.
+template <int BM, int BN, int WM, int WN, int XR>
+__global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs p) {
     constexpr int TM = BM / (32 * WM);
     constexpr int TN = BN / (32 * WN);
+    constexpr int WR = (KSTAGE * BM / 4 + 255) / 256;  // float4 weight loads per thread per stage
     static_assert(WM * WN == 4, "4 waves per workgroup");
     HIP_DYNAMIC_SHARED(float, smem)
     float* xs = smem;
@@ -84,94 +91,164 @@ __global__ void __launch_bounds__(256) conv_mfma_kernel(ConvArgs p) {
     const float* wg = p.w + (long)g * p.w_group_stride;
     const int hin0 = h0 * p.sh - p.ph, win0 = w0 * p.sw - p.pw;
     const int a_off = wm * (TM * 32) + l31 + half * BM;
-    const int xs_total = p.BKC * p.CHS;
+    const int stages_per_chunk = (p.taps + p.TT - 1) / p.TT;
+    const int nstages = p.nchunk * stages_per_chunk;
 
-    for (int c = 0; c < p.nchunk; ++c) {
-        __syncthreads();  // every wave is done reading the previous chunk's tiles
-        // ---- stage BKC channels of the input patch (halo included), pre-activation fused ----------
-        for (int idx = tid; idx < xs_total; idx += 256) {
-            const int ci = idx / p.CHS;
-            const int rem = idx - ci * p.CHS;
-            const int r = rem / p.TWp;
-            const int col = rem - r * p.TWp;
-            const int cg = c * p.BKC + ci;
-            const int hin = hin0 + r, win = win0 + col;
-            float v = 0.f;
-            if (cg < p.Cin_g && col < p.TW_in && hin >= 0 && hin < p.H && win >= 0 && win < p.W) {
-                v = xg[(long)cg * p.x_sc + (long)hin * p.x_sh + win];
-                v = apply_act(v, p.pre_act, p.pre_slope);
-            }
-            xs[idx] = v;
+    float xv[XR];
+    float4 wv[WR];
+
+    // ---- issue the global loads of one stage (no waits here) --------------------------------------------------
+    auto prefetch = [&](int st) {
+        const int c = st / stages_per_chunk;
+        const int tap0 = (st - c * stages_per_chunk) * p.TT;
+        const int rows = imin(p.TT, p.taps - tap0) << p.BKClog2;
+        // packed weights: [tap][Cin_pad][Mpad]; stage row r = (tap tt = r / BKC, channel c*BKC + r % BKC)
+        const float* wrow0 = wg + ((long)tap0 * p.Cin_pad + (long)c * p.BKC) * p.Mpad;
+#pragma unroll
+        for (int e = 0; e < WR; ++e) {
+            const int idx4 = tid + e * 256;
+            const int r = idx4 / (BM / 4);
+            const int c4 = idx4 - r * (BM / 4);
+            const int mcol = m_base + c4 * 4;
+            const int tt = r >> p.BKClog2, ci = r & (p.BKC - 1);
+            // branch-free: out-of-range slots re-read the first row and are zeroed afterwards
+            const bool ok = r < rows && mcol < p.Mpad;
+            const long off = ok ? ((long)tt * p.Cin_pad + ci) * p.Mpad + mcol : 0;
+            const float4 t = *reinterpret_cast<const float4*>(wrow0 + off);
+            wv[e] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        int kh = 0, kw = 0;
-        for (int tap0 = 0; tap0 < p.taps; tap0 += p.TT) {
-            const int nt = imin(p.TT, p.taps - tap0);
-            const int rows = nt * p.BKC;
-            if (tap0 > 0) __syncthreads();  // previous weight stage fully consumed
-            // ---- stage `rows` packed weight rows x BM columns (float4, coalesced) ---------------------
-            const float* wrow0 = wg + ((long)c * p.taps + tap0) * p.BKC * p.Mpad;
-            for (int idx4 = tid; idx4 < rows * (BM / 4); idx4 += 256) {
-                const int r = idx4 / (BM / 4);
-                const int c4 = idx4 - r * (BM / 4);
-                const int mcol = m_base + c4 * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (mcol < p.Mpad) v = *reinterpret_cast<const float4*>(wrow0 + (long)r * p.Mpad + mcol);
-                *reinterpret_cast<float4*>(ws + r * BM + c4 * 4) = v;
-            }
-            __syncthreads();
-            // ---- MFMA over the staged K rows ----------------------------------------------------------
-            for (int tt = 0; tt < nt; ++tt) {
-                const int tapoff = kh * p.dh * p.TWp + kw * p.dw;
-                const float* wt = ws + tt * p.BKC * BM + a_off;
-                const float* xt = xs + tapoff;
-                for (int kk = 0; kk < p.BKC; kk += 2) {
-                    float a[TM], b[TN];
+        if (tap0 == 0) {  // a new channel chunk: its input patch (halo included)
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) a[i] = wt[kk * BM + i * 32];
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) b[j] = xt[kk * p.CHS + boff[j]];
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-                }
-                if (++kw == p.KW) { kw = 0; ++kh; }
+            for (int e = 0; e < XR; ++e) {
+                const int idx = tid + e * 256;
+                const int ci = (int)__umulhi((unsigned)idx, p.div_chs);
+                const int rem = idx - ci * p.CHS;
+                const int r = (int)__umulhi((unsigned)rem, p.div_twp);
+                const int col = rem - r * p.TWp;
+                const int cg = c * p.BKC + ci;
+                const int hin = hin0 + r, win = win0 + col;
+                const bool ok = idx < p.xs_total && cg < p.Cin_g && col < p.TW_in && hin >= 0 && hin < p.H && win >= 0 && win < p.W;
+                const long off = ok ? (long)cg * p.x_sc + (long)hin * p.x_sh + win : 0;  // branch-free zero padding
+                const float t = xg[off];
+                xv[e] = ok ? t : 0.f;
             }
         }
+    };
+    // ---- registers -> LDS (pre-activation fused once per staged element) ---------------------------------------
+    auto commit = [&](int st) {
+        const int c = st / stages_per_chunk;
+        const int tap0 = (st - c * stages_per_chunk) * p.TT;
+#pragma unroll
+        for (int e = 0; e < WR; ++e) {
+            const int idx4 = tid + e * 256;
+            if (idx4 < KSTAGE * (BM / 4)) *reinterpret_cast<float4*>(ws + idx4 * 4) = wv[e];
+        }
+        if (tap0 == 0) {
+#pragma unroll
+            for (int e = 0; e < XR; ++e) {
+                const int idx = tid + e * 256;
+                if (idx < p.xs_total) xs[idx] = apply_act(xv[e], p.pre_act, p.pre_slope);
+            }
+        }
+    };
+
+    prefetch(0);
+    for (int st = 0; st < nstages; ++st) {
+        __syncthreads();  // every wave has finished the MFMAs of the previous stage: LDS may be overwritten
+        commit(st);
+        __syncthreads();
+        if (st + 1 < nstages) prefetch(st + 1);  // in flight during the MFMA loop below
+
+        const int c = st / stages_per_chunk;
+        const int tap0 = (st - c * stages_per_chunk) * p.TT;
+        const int nt = imin(p.TT, p.taps - tap0);
+        int kh0 = tap0 / p.KW, kw0 = tap0 - kh0 * p.KW;  // first tap of this stage
+        const int nsteps = nt * (p.BKC >> 1);  // MFMA k-steps of this stage
+        const float* wt = ws + a_off;
+        // Two fragment register sets used alternately (even / odd k-step): the LDS reads of step s+1 are issued
+        // before the MFMAs of step s, and each MFMA group waits only for its own (older) reads -- the in-order
+        // lgkm counter lets the newer reads stay in flight.
+        float a0[TM], b0[TN], a1[TM], b1[TN];
+        int kh = kh0, kw = kw0, kk = 0;  // (tap, channel pair) of the step being fetched
+        auto fetch = [&](float (&a)[TM], float (&b)[TN], int s) {
+            const float* xt = xs + kh * p.dh * p.TWp + kw * p.dw + kk * p.CHS;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = wt[s * 2 * BM + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = xt[boff[j]];
+            kk += 2;
+            if (kk == p.BKC) { kk = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
+        };
+        auto mma = [&](float (&a)[TM], float (&b)[TN]) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        };
+        fetch(a0, b0, 0);
+        int s = 0;
+        for (; s + 2 <= nsteps; s += 2) {
+            fetch(a1, b1, s + 1);
+            mma(a0, b0);
+            fetch(a0, b0, s + 2);  // unconditional: past the last step this reads (never uses) the LDS slack rows
+            mma(a1, b1);
+        }
+        if (s < nsteps) mma(a0, b0);  // odd step count (BKC = 2 with an odd number of taps)
     }
 
     // ---- epilogue: y = [y +] out_scale * (act(acc + bias [+ res]) [+ res]) ------------------------------------
+    // res / y may alias (in-place residual), so the compiler cannot move a load across a store: all operand loads
+    // of a 32x32 tile are issued first, then the 16 results per lane are formed and stored.
     const long y_base = (long)n * p.y_sn, r_base = (long)n * p.r_sn;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int nl = wn * (TN * 32) + j * 32 + l31;
         const int ho = h0 + (nl >> p.TWlog2), wo = w0 + (nl & (p.TW - 1));
-        if (ho >= p.Ho || wo >= p.Wo) continue;
+        const bool col_ok = ho < p.Ho && wo < p.Wo;
+        const long y_col = y_base + (long)ho * p.y_sh + wo, r_col = r_base + (long)ho * p.r_sh + wo;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            const int m0 = m_base + wm * (TM * 32) + i * 32 + 4 * half;
+            float rv[16], yv[16], bv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m_base + wm * (TM * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m >= p.Cout_g) continue;
+                const int m = m0 + (r & 3) + 8 * (r >> 2);
+                const bool ok = col_ok && m < p.Cout_g;
                 const int co = g * p.Cout_g + m;
-                float v = acc[i][j][r];
-                if (p.bias) v += p.bias[co];
-                float rv = 0.f;
-                if (p.res) rv = p.res[r_base + (long)co * p.r_sc + (long)ho * p.r_sh + wo];
-                if (p.res_first) v += rv;
+                bv[r] = (ok && p.bias) ? p.bias[co] : 0.f;
+                rv[r] = (ok && p.res) ? p.res[r_col + (long)co * p.r_sc] : 0.f;
+                yv[r] = (ok && p.accumulate) ? p.y[y_col + (long)co * p.y_sc] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (r & 3) + 8 * (r >> 2);
+                if (!(col_ok && m < p.Cout_g)) continue;
+                const int co = g * p.Cout_g + m;
+                float v = acc[i][j][r] + bv[r];
+                if (p.res_first) v += rv[r];
                 v = apply_act(v, p.act, p.act_slope);
-                if (!p.res_first) v += rv;
-                v *= p.out_scale;
-                float* yp = p.y + y_base + (long)co * p.y_sc + (long)ho * p.y_sh + wo;
-                if (p.accumulate) v += *yp;
-                *yp = v;
+                if (!p.res_first) v += rv[r];
+                p.y[y_col + (long)co * p.y_sc] = v * p.out_scale + yv[r];
             }
         }
     }
 }
 
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+static unsigned div_mul(int d) { return (unsigned)((0x100000000ULL + (unsigned long long)d - 1) / (unsigned long long)d); }
+
+template <int BM, int BN, int WM, int WN, int XR>
+static int launch_conv_xr(ConvArgs& p, hipStream_t stream, size_t lds) {
+    auto kern = conv_mfma_kernel<BM, BN, WM, WN, XR>;
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const long gx = (long)p.N * p.tiles_h * p.tiles_w;
+    if (gx > 2147483647L) return fail(AICG_E_SHAPE, "conv: too many output tiles");
+    dim3 grid((unsigned)gx, (unsigned)idiv_up(p.Cout_g, BM), (unsigned)p.groups);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
+    return check_launch("conv_mfma_kernel");
+}
 
 template <int BM, int BN, int WM, int WN>
 static int launch_conv(ConvArgs& p, hipStream_t stream) {
@@ -188,19 +265,30 @@ static int launch_conv(ConvArgs& p, hipStream_t stream) {
     p.CHS = p.TH_in * p.TWp;
     p.tiles_w = idiv_up(p.Wo, p.TW);
     p.tiles_h = idiv_up(p.Ho, p.TH);
-    p.xs_elems = (p.BKC * p.CHS + 3) & ~3;
-    const size_t lds = (size_t)(p.xs_elems + KSTAGE * BM) * sizeof(float);
-    if (lds > 160 * 1024)
-        return fail(AICG_E_LDS, "conv: input patch of %d x %d x %d floats does not fit LDS (use aicg_conv1d_cin1 for Cin=1)",
-                    p.BKC, p.TH_in, p.TWp);
-    auto kern = conv_mfma_kernel<BM, BN, WM, WN>;
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const long gx = (long)p.N * p.tiles_h * p.tiles_w;
-    if (gx > 2147483647L) return fail(AICG_E_SHAPE, "conv: too many output tiles");
-    dim3 grid((unsigned)gx, (unsigned)idiv_up(p.Cout_g, BM), (unsigned)p.groups);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
-    return check_launch("conv_mfma_kernel");
+    // channels per K chunk: as many as keep the staged patch within 8 prefetch registers per thread (2048 floats)
+    // and a weight stage within KSTAGE rows; never (much) more than the layer has
+    p.BKC = 32;
+    while (p.BKC > 2 && (p.BKC * p.CHS > 12 * 256 || p.BKC >= 2 * p.Cin_g)) p.BKC >>= 1;
+    p.BKClog2 = ilog2(p.BKC);
+    {   // taps per weight stage: as few, equally sized stages per chunk as fit KSTAGE rows
+        const int cap = imax(1, KSTAGE / p.BKC);
+        const int nstg = idiv_up(p.taps, cap);
+        p.TT = idiv_up(p.taps, nstg);
+    }
+    p.nchunk = idiv_up(p.Cin_g, p.BKC);
+    p.xs_total = p.BKC * p.CHS;
+    p.xs_elems = (p.xs_total + 3) & ~3;
+    p.div_chs = div_mul(p.CHS);
+    p.div_twp = div_mul(p.TWp);
+    // + 2 weight rows of slack: the MFMA loop's last (discarded) fragment prefetch reads one k-step past the stage
+    const size_t lds = (size_t)(p.xs_elems + (KSTAGE + 2) * BM) * sizeof(float);
+    const int xr = idiv_up(p.xs_total, 256);
+    if (lds > 160 * 1024 || (long)p.xs_total * p.CHS >= (1L << 32))
+        return fail(AICG_E_LDS, "conv: input patch of %d x %d x %d floats is too large for one workgroup (stride/kernel too big: "
+                                "re-express the layer with the phase decomposition used for Cin = 1 convs)", p.BKC, p.TH_in, p.TWp);
+    if (xr <= 8) return launch_conv_xr<BM, BN, WM, WN, 8>(p, stream, lds);
+    if (xr <= 12) return launch_conv_xr<BM, BN, WM, WN, 12>(p, stream, lds);
+    return fail(AICG_E_LDS, "conv: a 2-channel input patch of %d floats exceeds the staging budget", p.xs_total);
 }
 
 }  // namespace aicg
@@ -208,10 +296,9 @@ static int launch_conv(ConvArgs& p, hipStream_t stream) {
 using namespace aicg;
 
 extern "C" int aicg_conv_bkc(int taps) {
-    // channels per K chunk: keep a weight stage at KSTAGE = 32 rows (TT taps x BKC channels)
-    if (taps <= 1) return 32;
-    if (taps <= 3) return 16;
-    return 8;
+    // granularity to which the packed weights pad the input-channel axis (the kernel picks its K chunk <= this)
+    (void)taps;
+    return 32;
 }
 
 extern "C" int aicg_conv_desc_size(void) { return (int)sizeof(aicg_conv_desc); }
@@ -241,28 +328,35 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
     p.pre_act = d->pre_act; p.pre_slope = d->pre_slope; p.act = d->act; p.act_slope = d->act_slope;
     p.out_scale = d->out_scale; p.accumulate = d->accumulate; p.res_first = d->res_before_act;
     p.taps = p.KH * p.KW;
-    p.BKC = aicg_conv_bkc(p.taps);
-    p.TT = KSTAGE / p.BKC;
-    p.nchunk = idiv_up(p.Cin_g, p.BKC);
     p.Mpad = idiv_up(p.Cout_g, 32) * 32;
-    p.w_group_stride = (long)p.nchunk * p.taps * p.BKC * p.Mpad;
+    p.Cin_pad = idiv_up(p.Cin_g, 32) * 32;
+    p.w_group_stride = (long)p.taps * p.Cin_pad * p.Mpad;
 
-    // tile shape: smallest padded M, then enough workgroups to fill 256 CUs
+    // tile shape: the BM in {160, 128, 96, 64, 32} with the least padded M (larger BM on ties: one input patch
+    // staging feeds more MFMAs), then enough workgroups to fill 256 CUs
     const int M = p.Cout_g;
-    int BM = 128;
+    int BM = 32;
     {
-        int best = idiv_up(M, 128) * 128;
-        if (idiv_up(M, 64) * 64 < best) { best = idiv_up(M, 64) * 64; BM = 64; }
-        if (idiv_up(M, 32) * 32 < best) { best = idiv_up(M, 32) * 32; BM = 32; }
+        long best = 1L << 40;
+        const int cands[5] = {160, 128, 96, 64, 32};
+        for (int i = 0; i < 5; ++i) {
+            const long padded = (long)idiv_up(M, cands[i]) * cands[i];
+            if (padded < best) { best = padded; BM = cands[i]; }
+        }
     }
     const long npos = (long)p.N * Ho * Wo;
-    const long mt = idiv_up(M, BM) * (long)p.groups;
     hipStream_t st = (hipStream_t)stream;
-    if (BM == 128) return launch_conv<128, 128, 2, 2>(p, st);
-    if (BM == 64) {
-        if (mt * ldiv_up(npos, 128) < 512) return launch_conv<64, 64, 2, 2>(p, st);
-        return launch_conv<64, 128, 2, 2>(p, st);
+    // A launch should give each of the 256 CUs at least ~2 workgroups: shrink the tile for small problems
+    // (HuBERT / enc_p GEMMs over a few thousand frames), M first (keeps the wide, coalesced N tile), then N.
+    auto blocks = [&](int bm, int bn) { return (long)idiv_up(M, bm) * p.groups * ldiv_up(npos, bn); };
+    const long want = 512;
+    if (BM == 160 && blocks(160, 128) >= want) return launch_conv<160, 128, 1, 4>(p, st);
+    if (BM == 128 && blocks(128, 128) >= want) return launch_conv<128, 128, 2, 2>(p, st);
+    if (BM == 96 && blocks(96, 128) >= want) return launch_conv<96, 128, 1, 4>(p, st);
+    if (M > 32) {
+        if (blocks(64, 128) >= want) return launch_conv<64, 128, 2, 2>(p, st);
+        if (blocks(64, 64) >= want || M > 64) return launch_conv<64, 64, 2, 2>(p, st);
     }
-    if (mt * ldiv_up(npos, 256) < 512) return launch_conv<32, 128, 1, 4>(p, st);
-    return launch_conv<32, 256, 1, 4>(p, st);
+    if (blocks(32, 256) >= want) return launch_conv<32, 256, 1, 4>(p, st);
+    return launch_conv<32, 128, 1, 4>(p, st);
 }

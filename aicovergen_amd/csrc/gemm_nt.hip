@@ -31,8 +31,8 @@ static constexpr int GLD = GK + 1;   // LDS row stride
 
 // 128 x 128 tile, 4 waves as 2 x 2, each wave 64 x 64 (2 x 2 MFMA tiles)
 __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmArgs p) {
-    __shared__ float As[128 * GLD];
-    __shared__ float Ws[128 * GLD];
+    __shared__ float As[128 * GLD + 4];
+    __shared__ float Ws[128 * GLD + 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int wm = wave >> 1, wn = wave & 1;
@@ -46,29 +46,61 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // Software pipeline as in conv.hip: the float4 global loads of K-slab s+1 are issued right after the barrier that
+    // publishes slab s and land while its MFMAs run; fragments alternate between two register sets.
+    float4 av[4], wv[4];
+    auto prefetch = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + e * 256;          // 128 rows x 8 float4
+            const int row = idx >> 3, k = k0 + (idx & 7) * 4;
+            const long r = r0 + row;
+            const int o = o0 + row;
+            av[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            wv[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < p.R && k < p.K) av[e] = *reinterpret_cast<const float4*>(p.a + r * p.lda + k);
+            if (o < p.O && k < p.K) wv[e] = *reinterpret_cast<const float4*>(p.w + (long)o * p.ldw + k);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + e * 256;
+            const int row = idx >> 3, kk = (idx & 7) * 4;
+            float* pa = As + row * GLD + kk;
+            float* pw = Ws + row * GLD + kk;
+            pa[0] = av[e].x; pa[1] = av[e].y; pa[2] = av[e].z; pa[3] = av[e].w;
+            pw[0] = wv[e].x; pw[1] = wv[e].y; pw[2] = wv[e].z; pw[3] = wv[e].w;
+        }
+    };
+    const float* ap = As + (wm * 64 + l31) * GLD + half;
+    const float* wp = Ws + (wn * 64 + l31) * GLD + half;
+    prefetch(0);
     for (int k0 = 0; k0 < p.K; k0 += GK) {
         __syncthreads();
-        // stage 128 rows x 32 k of A and of W: consecutive lanes read consecutive k (coalesced 128-byte rows)
-        for (int idx = tid; idx < 128 * GK; idx += 256) {
-            const int row = idx >> 5, kk = idx & 31;
-            const int k = k0 + kk;
-            const long r = r0 + row;
-            As[row * GLD + kk] = (r < p.R && k < p.K) ? p.a[r * p.lda + k] : 0.f;
-            const int o = o0 + row;
-            Ws[row * GLD + kk] = (o < p.O && k < p.K) ? p.w[(long)o * p.ldw + k] : 0.f;
-        }
+        commit();
         __syncthreads();
-#pragma unroll 4
-        for (int kk = 0; kk < GK; kk += 2) {
-            float a[2], b[2];
+        if (k0 + GK < p.K) prefetch(k0 + GK);
+        float a0[2], b0[2], a1[2], b1[2];
+        auto fetch = [&](float (&a)[2], float (&b)[2], int kk) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = As[(wm * 64 + i * 32 + l31) * GLD + kk + half];
+            for (int i = 0; i < 2; ++i) a[i] = ap[i * 32 * GLD + kk];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = Ws[(wn * 64 + j * 32 + l31) * GLD + kk + half];
+            for (int j = 0; j < 2; ++j) b[j] = wp[j * 32 * GLD + kk];
+        };
+        auto mma = [&](float (&a)[2], float (&b)[2]) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        };
+        fetch(a0, b0, 0);
+#pragma unroll
+        for (int kk = 0; kk < GK; kk += 4) {
+            fetch(a1, b1, kk + 2);
+            mma(a0, b0);
+            fetch(a0, b0, kk + 4);  // kk + 4 == GK reads the (unused) pad column of the next row: in bounds
+            mma(a1, b1);
         }
     }
     // D layout: col (n = o) = lane & 31, row (m = r) = (reg & 3) + 8 * (reg >> 2) + 4 * half
@@ -106,6 +138,8 @@ extern "C" int aicg_gemm_nt(const float* a, const float* w, const float* bias, c
     if (R < 0 || K < 1 || O < 1) return fail(AICG_E_SHAPE, "aicg_gemm_nt: bad shape");
     if ((row_scale != nullptr) != (row_shift != nullptr) || (row_scale && (rows_per_ch < 1 || n_ch < 1)))
         return fail(AICG_E_ARG, "aicg_gemm_nt: row affine needs scale, shift, rows_per_ch and n_ch");
+    if ((K & 3) || (lda & 3) || (ldw & 3))
+        return fail(AICG_E_SHAPE, "aicg_gemm_nt: K, lda and ldw must be multiples of 4 (float4 loads)");
     if (R == 0) return AICG_OK;
     GemmArgs p{a, w, bias, row_scale, row_shift, res, c, (long)R, K, O, (long)lda, (long)ldw, (long)ldc, (long)ldr,
                rows_per_ch, n_ch, act};

@@ -126,20 +126,16 @@ def conv_bkc(taps):
 
 
 def pack_conv_weight(w, groups=1):
-    """(Cout, Cin/groups, KH, KW) -> per group [chunk][tap][channel in chunk][Mpad] (pure re-layout + zero pad)."""
+    """(Cout, Cin/groups, KH, KW) -> per group [tap][Cin_pad][Mpad] (pure re-layout + zero pad; Cin_pad and Mpad are
+    multiples of 32)."""
     w = w.detach().to(torch.float32)
     cout, cin_g, kh, kw = w.shape
     taps = kh * kw
-    bkc = conv_bkc(taps)
+    cpad = (cin_g + 31) // 32 * 32
     cout_g = cout // groups
     mpad = (cout_g + 31) // 32 * 32
-    nchunk = (cin_g + bkc - 1) // bkc
-    wg = w.reshape(groups, cout_g, cin_g, taps)
-    wp = torch.zeros((groups, cout_g, nchunk * bkc, taps), dtype=torch.float32, device=w.device)
-    wp[:, :, :cin_g] = wg
-    wp = wp.reshape(groups, cout_g, nchunk, bkc, taps).permute(0, 2, 4, 3, 1)  # g, chunk, tap, ci, co
-    out = torch.zeros((groups, nchunk, taps, bkc, mpad), dtype=torch.float32, device=w.device)
-    out[..., :cout_g] = wp
+    out = torch.zeros((groups, taps, cpad, mpad), dtype=torch.float32, device=w.device)
+    out[:, :, :cin_g, :cout_g] = w.reshape(groups, cout_g, cin_g, taps).permute(0, 3, 2, 1)
     return out.contiguous()
 
 
@@ -181,6 +177,25 @@ def _as4d(t):
     return t.unsqueeze(2) if t.dim() == 3 else t
 
 
+class ConvProfile:
+    """Optional per-launch accounting of the conv kernel (bench.py roofline): algorithmic FLOPs and HIP-event time of
+    every aicg_conv_forward launch on the current stream.  Enabled with `ops.conv_profile = ConvProfile()`."""
+
+    def __init__(self):
+        self.events = []
+        self.flops = 0.0
+        self.launches = 0
+
+    def summary(self):
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self.events)
+        return {"launches": self.launches, "flops": self.flops, "ms": ms,
+                "tflops": (self.flops / (ms * 1e-3) / 1e12) if ms > 0 else 0.0}
+
+
+conv_profile = None
+
+
 def conv(x, pc, res=None, out=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NONE, act_slope=0.0, out_scale=1.0,
          accumulate=False, bias=None, res_before_act=False, out_len=None):
     """y = [y +] out_scale * (act(conv(pre_act(x)) + bias) + res).  x: (N,C,T) or (N,C,H,W), last dim contiguous;
@@ -220,7 +235,16 @@ def conv(x, pc, res=None, out=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NON
     d.pre_act, d.pre_slope, d.act, d.act_slope = pre_act, pre_slope, act, act_slope
     d.out_scale, d.accumulate = out_scale, 1 if accumulate else 0
     d.res_before_act = 1 if res_before_act else 0
+    prof = conv_profile
+    if prof is not None and x.is_cuda:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.call("aicg_conv_forward", ctypes.addressof(d), _ptr(x4), _ptr(pc.w), _ptr(b), _ptr(r4), _ptr(o4), _stream(x))
+    if prof is not None and x.is_cuda:
+        e1.record()
+        prof.events.append((e0, e1))
+        prof.flops += 2.0 * n * pc.cout * (pc.cin // pc.groups) * pc.kh * pc.kw * ho * wo
+        prof.launches += 1
     return out
 
 

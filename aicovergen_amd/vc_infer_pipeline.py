@@ -199,6 +199,7 @@ class VC(object):
             except Exception:
                 traceback.print_exc()
                 index = big_npy = None
+        tp0 = ttime()
         audio, audio_pad, opt_ts, p_len = self.plan(audio)
         t1 = ttime()
         inp_f0 = None
@@ -236,6 +237,7 @@ class VC(object):
             out = self.vc(model, net_g, sid, audio_pad[s:e], pc, pcf, times, index, big_npy, index_rate, version, protect,
                           noise=noise)
             pieces[ci] = out[self.t_pad_tgt: -self.t_pad_tgt]
+        tc1 = ttime()
         pieces = adist.gather_pieces(pieces, len(bounds), self.device, group)
         audio_opt = np.concatenate([pieces[i] for i in range(len(bounds))])
         if rms_mix_rate != 1:
@@ -249,6 +251,8 @@ class VC(object):
         if audio_max > 1:
             max_int16 /= audio_max
         audio_opt = (audio_opt * max_int16).astype(np.int16)
+        # wall-clock split of this call (host pre-processing, f0, chunk loop, join + host post-processing)
+        self.last_profile = {"plan_s": t1 - tp0, "f0_s": t2 - t1, "chunks_s": tc1 - t2, "post_s": ttime() - tc1}
         return audio_opt
 
 

@@ -83,7 +83,7 @@ int aicg_istft_ola(const float* frames, const float* window, float* out, int n_s
  *                                       + res[n,co,ho,wo] )
  * 1-D convolutions use H = KH = 1.  Strides are in elements; W is contiguous for x, y and res.
  * Weights must be packed with the layout of aicovergen_amd.ops.pack_conv_weight (per group:
- * [ceil(Cin_g/BKC)][KH*KW][BKC][Mpad], BKC = aicg_conv_bkc(KH*KW), Mpad = roundup(Cout_g, 32)).
+ * [KH*KW][Cin_pad][Mpad], Cin_pad = roundup(Cin_g, 32), Mpad = roundup(Cout_g, 32)).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct aicg_conv_desc {
     int32_t N, Cin, H, W;

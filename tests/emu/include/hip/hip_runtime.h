@@ -199,6 +199,7 @@ inline emu_f32x4 emu_mfma_f32_16x16x4f32(float a, float b, emu_f32x4 c, int, int
 #define __builtin_amdgcn_s_barrier() ::emu::block_barrier()
 
 // ---- device math ---------------------------------------------------------------------------------
+inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 inline float __expf(float x) { return expf(x); }
 inline float __logf(float x) { return logf(x); }
 inline float __fdividef(float a, float b) { return a / b; }

@@ -53,6 +53,38 @@ conv_case("ffn_192_768_k3_T6600", 192, 768, 3, 1, 6600, fused=False)
 conv_case("hubert_fe_512_k3_s2", 512, 512, 3, 1, 105615, stride=2, fused=False)
 conv_case("posconv_768_k128_g16", 768, 768, 128, 1, 3300, groups=16, fused=False)
 
+
+
+def conv2d_case(name, n, ci, co, H, W, k=3):
+    x = torch.randn(n, ci, H, W, device=dev)
+    pc = ops.PackedConv(torch.randn(co, ci, k, k) * 0.05, torch.randn(co), padding=k // 2, device=dev)
+    out = torch.empty(n, co, H, W, device=dev)
+    t = timeit(lambda: ops.conv(x, pc, out=out, act=ops.ACT_RELU), iters=5)
+    fl = 2.0 * n * co * ci * k * k * H * W
+    res[name] = {"ms": t * 1e3, "tflops": fl / t / 1e12}
+    print(name, res[name], flush=True)
+
+
+# MDX-Net TFC convs per level (batch 16 = 8 windows x {+,-}) and RMVPE levels
+conv2d_case("mdx_L0_c48", 16, 48, 48, 256, 3072)
+conv2d_case("mdx_L1_c96", 16, 96, 96, 128, 1536)
+conv2d_case("mdx_L2_c144", 16, 144, 144, 64, 768)
+conv2d_case("mdx_L3_c192", 16, 192, 192, 32, 384)
+conv2d_case("mdx_L4_c240", 16, 240, 240, 16, 192)
+conv2d_case("mdx_mid_c288", 16, 288, 288, 8, 96)
+conv2d_case("rmvpe_L0_c16", 1, 16, 16, 24608, 128)
+conv2d_case("rmvpe_L2_c64", 1, 64, 64, 6152, 32)
+conv2d_case("rmvpe_L4_c256", 1, 256, 256, 1538, 8)
+conv2d_case("rmvpe_mid_c512", 1, 512, 512, 769, 4)
+# TDF linear (level 0): rows = 16*48*256, K = 3072 -> 384 -> 3072
+xg = torch.randn(16, 48, 256, 3072, device=dev)
+w1 = torch.randn(384, 3072, device=dev) * 0.02
+sc, sh = torch.ones(48, device=dev), torch.zeros(48, device=dev)
+t = timeit(lambda: ops.linear_last(xg, w1, None, sc, sh, act=ops.ACT_RELU), iters=5)
+res["tdf_L0_3072_384"] = {"ms": t * 1e3, "tflops": 2.0 * 16 * 48 * 256 * 3072 * 384 / t / 1e12}
+print("tdf", res["tdf_L0_3072_384"], flush=True)
+del xg
+
 # STFT / iSTFT: one MDX window batch (22 windows x 2 channels), frame-major internal layout
 x = torch.randn(44, 261120, device=dev)
 t = timeit(lambda: ops.stft(x, 7680, 1024, 3072, frame_major=True))
