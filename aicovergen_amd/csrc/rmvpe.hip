@@ -41,35 +41,77 @@ __global__ void __launch_bounds__(256) avgpool2x2_kernel(const float* __restrict
 // ---- bidirectional GRU recurrence (torch.nn.GRU, 1 layer; rmvpe.py:11-20) --------------------------------------
 // gi: (2*3*Hd, T) = W_ih x + b_ih for [forward r,z,n ; reverse r,z,n], channel-major (computed by the conv kernel)
 // whh_t: (2, Hd, 3*Hd) = W_hh transposed per direction (k-major, so lane j reads unit-stride)
-// out: (2*Hd, T).  One workgroup per direction; h lives in LDS, W_hh streams from L2 each step.
+// out: (2*Hd, T).  One workgroup per direction, one thread per gate row; the T steps are strictly sequential, so
+// the cost per step is the cost of reading W_hh (3*Hd x Hd fp32 = 786 KB for Hd = 256, more than one CU's register
+// file): each thread keeps the first KR columns of its row in registers, the next KL columns of all rows sit in
+// LDS, and only the remaining Hd - KR - KL columns stream from L2 every step.
 //   r = s(gi_r + W_hr h + b_hr); z = s(gi_z + W_hz h + b_hz); n = tanh(gi_n + r*(W_hn h + b_hn)); h = (1-z)*n + z*h
-template <int HD>
-__global__ void __launch_bounds__(3 * HD) gru_kernel(const float* __restrict__ gi, const float* __restrict__ whh_t,
-                                                     const float* __restrict__ bhh, float* __restrict__ out, long T) {
-    __shared__ float h[HD];
-    __shared__ float gh[3 * HD];
+template <int HD, int KR, int KL>
+__global__ void __launch_bounds__(3 * HD / 2) gru_kernel(const float* __restrict__ gi, const float* __restrict__ whh_t,
+                                                         const float* __restrict__ bhh, float* __restrict__ out, long T) {
+    // 3*HD/2 threads, two gate rows each (j and j + 3*HD/2): 6 waves for HD = 256 leave each wave a 256-register
+    // budget, of which 2*KR hold weights.
+    constexpr int NT = 3 * HD / 2;
+    HIP_DYNAMIC_SHARED(float, smem)
+    float* h = smem;               // HD
+    float* gh = smem + HD;         // 3*HD
+    float* wl = smem + 4 * HD;     // KL x 3*HD
     const int dir = blockIdx.x;
-    const int j = threadIdx.x;  // gate row 0..3*HD-1
+    const int j0 = threadIdx.x, j1 = threadIdx.x + NT;  // gate rows of this thread
     const float* W = whh_t + (long)dir * HD * 3 * HD;
-    const float bj = bhh[dir * 3 * HD + j];
+    const float b0 = bhh[dir * 3 * HD + j0], b1 = bhh[dir * 3 * HD + j1];
     const float* gid = gi + (long)dir * 3 * HD * T;
     float* od = out + (long)dir * HD * T;
-    if (j < HD) h[j] = 0.f;
+    float w0[KR], w1[KR];
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+        w0[k] = W[(long)k * 3 * HD + j0];
+        w1[k] = W[(long)k * 3 * HD + j1];
+    }
+    for (int k = 0; k < KL; ++k) {
+        wl[k * 3 * HD + j0] = W[(long)(KR + k) * 3 * HD + j0];
+        wl[k * 3 * HD + j1] = W[(long)(KR + k) * 3 * HD + j1];
+    }
+    if (j0 < HD) h[j0] = 0.f;
     __syncthreads();
     for (long s = 0; s < T; ++s) {
         const long t = dir == 0 ? s : T - 1 - s;
-        float acc = bj;
-#pragma unroll 8
-        for (int k = 0; k < HD; ++k) acc = fmaf(W[(long)k * 3 * HD + j], h[k], acc);
-        gh[j] = acc;
+        // the input projections of this step are independent of h: issue their loads before the dot products
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+        if (j0 < HD) {
+            g0 = gid[(long)j0 * T + t];
+            g1 = gid[(long)(HD + j0) * T + t];
+            g2 = gid[(long)(2 * HD + j0) * T + t];
+        }
+        float a0 = b0, a1 = b1;
+#pragma unroll
+        for (int k = 0; k < KR; ++k) {
+            const float hk = h[k];
+            a0 = fmaf(w0[k], hk, a0);
+            a1 = fmaf(w1[k], hk, a1);
+        }
+#pragma unroll 4
+        for (int k = 0; k < KL; ++k) {
+            const float hk = h[KR + k];
+            a0 = fmaf(wl[k * 3 * HD + j0], hk, a0);
+            a1 = fmaf(wl[k * 3 * HD + j1], hk, a1);
+        }
+#pragma unroll 4
+        for (int k = KR + KL; k < HD; ++k) {
+            const float hk = h[k];
+            a0 = fmaf(W[(long)k * 3 * HD + j0], hk, a0);
+            a1 = fmaf(W[(long)k * 3 * HD + j1], hk, a1);
+        }
+        gh[j0] = a0;
+        gh[j1] = a1;
         __syncthreads();
-        if (j < HD) {
-            const float r = 1.f / (1.f + expf(-(gid[(long)j * T + t] + gh[j])));
-            const float z = 1.f / (1.f + expf(-(gid[(long)(HD + j) * T + t] + gh[HD + j])));
-            const float n = tanhf(gid[(long)(2 * HD + j) * T + t] + r * gh[2 * HD + j]);
-            const float hn = (1.f - z) * n + z * h[j];
-            h[j] = hn;
-            od[(long)j * T + t] = hn;
+        if (j0 < HD) {
+            const float r = 1.f / (1.f + expf(-(g0 + gh[j0])));
+            const float z = 1.f / (1.f + expf(-(g1 + gh[HD + j0])));
+            const float n = tanhf(g2 + r * gh[2 * HD + j0]);
+            const float hn = (1.f - z) * n + z * h[j0];
+            h[j0] = hn;
+            od[(long)j0 * T + t] = hn;
         }
         __syncthreads();
     }
@@ -176,12 +218,20 @@ extern "C" int aicg_gru_bidir(const float* gi, const float* whh_t, const float* 
                               void* stream) {
     if (!gi || !whh_t || !bhh || !out) return fail(AICG_E_ARG, "aicg_gru_bidir: null pointer");
     if (T == 0) return AICG_OK;
-    if (hidden == 256)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(gru_kernel<256>), dim3(2), dim3(768), 0, (hipStream_t)stream, gi, whh_t, bhh, out, (long)T);
-    else if (hidden == 64)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(gru_kernel<64>), dim3(2), dim3(192), 0, (hipStream_t)stream, gi, whh_t, bhh, out, (long)T);
-    else
+    if (hidden == 256) {
+        constexpr int KR = 96, KL = 48;
+        const size_t lds = (size_t)(4 * 256 + KL * 768) * sizeof(float);
+        auto kern = gru_kernel<256, KR, KL>;
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(2), dim3(384), lds, (hipStream_t)stream, gi, whh_t, bhh, out, (long)T);
+    } else if (hidden == 64) {
+        constexpr int KR = 32, KL = 16;
+        const size_t lds = (size_t)(4 * 64 + KL * 192) * sizeof(float);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gru_kernel<64, KR, KL>), dim3(2), dim3(96), lds, (hipStream_t)stream, gi, whh_t, bhh,
+                           out, (long)T);
+    } else {
         return fail(AICG_E_SHAPE, "aicg_gru_bidir: hidden size %d not instantiated (256, 64)", hidden);
+    }
     return check_launch("gru_kernel");
 }
 

@@ -52,10 +52,9 @@ def mdx_separate(mdx_sess, wave, denoise, m_threads=2, group=None):
 
 
 def gather_pieces(pieces, total, device, group=None):
-    """RVC join: `pieces` maps chunk index -> 1-D float32 numpy array for the chunks this rank converted
+    """RVC join: `pieces` maps chunk index -> 1-D float32 device tensor for the chunks this rank converted
     (round-robin ownership: chunk i belongs to rank i % world).  Every rank gets all `total` pieces: lengths are
     exchanged first, then one all_gather of equal-size padded blocks."""
-    import numpy as np
     rank, ws = world(group)
     if ws == 1:
         return pieces
@@ -64,7 +63,7 @@ def gather_pieces(pieces, total, device, group=None):
     for r in range(rounds):
         ci = r * ws + rank
         if ci in pieces:
-            lens[r] = len(pieces[ci])
+            lens[r] = pieces[ci].numel()
     all_lens = [torch.empty_like(lens) for _ in range(ws)]
     td.all_gather(all_lens, lens, group=group)
     maxlen = int(torch.stack(all_lens).max().item())
@@ -72,15 +71,14 @@ def gather_pieces(pieces, total, device, group=None):
     for r in range(rounds):
         ci = r * ws + rank
         if ci in pieces:
-            block[r, : len(pieces[ci])] = torch.from_numpy(np.ascontiguousarray(pieces[ci])).to(device)
+            block[r, : pieces[ci].numel()] = pieces[ci]
     blocks = [torch.empty_like(block) for _ in range(ws)]
     td.all_gather(blocks, block, group=group)
     out = {}
     for rk in range(ws):
-        bl = blocks[rk].cpu().numpy()
-        ln = all_lens[rk].cpu().numpy()
+        ln = all_lens[rk].cpu().tolist()
         for r in range(rounds):
             ci = r * ws + rk
             if ci < total:
-                out[ci] = bl[r, : int(ln[r])]
+                out[ci] = blocks[rk][r, : int(ln[r])]
     return out

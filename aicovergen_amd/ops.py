@@ -500,3 +500,62 @@ def axpbypcz(a, alpha, b=None, beta=0.0, c=None, gamma=0.0, out=None):
     _lib.call("aicg_axpbypcz", _ptr(a), float(alpha), _ptr(b), float(beta), _ptr(c), float(gamma), _ptr(out), a.numel(),
               _stream(a))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# VC.pipeline pre/post on the device
+# ---------------------------------------------------------------------------------------------------
+def box_sum_f64(x, n, window):
+    """x: float64 (n + window - 1,) -> out[j] = sum_{i<window} x[j+i] (reference summation order)."""
+    x = x.contiguous()
+    assert x.dtype == torch.float64 and x.numel() >= n + window - 1
+    out = torch.empty(n, dtype=torch.float64, device=x.device)
+    _check(x)
+    _lib.call("aicg_box_sum_f64", _ptr(x), _ptr(out), n, window, _stream(x))
+    return out
+
+
+def argmin_abs_f64(x, starts, lens):
+    """first index of min |x[s : s+l]| for each (s, l)."""
+    assert x.dtype == torch.float64
+    st = torch.tensor(list(starts), dtype=torch.int64, device=x.device)
+    ln = torch.tensor(list(lens), dtype=torch.int64, device=x.device)
+    out = torch.empty(len(st), dtype=torch.int64, device=x.device)
+    _check(x)
+    _lib.call("aicg_argmin_abs_f64", _ptr(x), _ptr(st), _ptr(ln), _ptr(out), len(st), _stream(x))
+    return out
+
+
+def frame_rms(x, frame_length, hop_length):
+    """librosa.feature.rms (center, reflect) of a 1-D float32 / float64 device tensor -> float64 (n_frames,)."""
+    x = x.contiguous()
+    assert x.dim() == 1 and x.dtype in (torch.float32, torch.float64)
+    n = x.numel()
+    out = torch.empty(1 + n // hop_length, dtype=torch.float64, device=x.device)
+    _check(x)
+    _lib.call("aicg_frame_rms", _ptr(x), 1 if x.dtype == torch.float64 else 0, _ptr(out), n, frame_length, hop_length, _stream(x))
+    return out
+
+
+def rms_mix_(data, rms1, rms2, rate):
+    assert data.is_contiguous() and data.dtype == torch.float32
+    _check(data, rms1, rms2)
+    _lib.call("aicg_rms_mix", _ptr(data), data.numel(), _ptr(rms1), rms1.numel(), _ptr(rms2), rms2.numel(), float(rate),
+              _stream(data))
+    return data
+
+
+def absmax(x):
+    assert x.is_contiguous() and x.dtype == torch.float32
+    out = torch.zeros(1, dtype=torch.float32, device=x.device)
+    _check(x)
+    _lib.call("aicg_absmax", _ptr(x), x.numel(), _ptr(out), _stream(x))
+    return out
+
+
+def to_int16(x, scale):
+    assert x.is_contiguous() and x.dtype == torch.float32
+    out = torch.empty(x.shape, dtype=torch.int16, device=x.device)
+    _check(x)
+    _lib.call("aicg_to_int16", _ptr(x), _ptr(out), x.numel(), float(scale), _stream(x))
+    return out

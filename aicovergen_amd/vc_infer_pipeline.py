@@ -107,9 +107,10 @@ class VC(object):
 
     # ---- one chunk ----------------------------------------------------------------------------------------------
     def vc(self, model, net_g, sid, audio0, pitch, pitchf, times, index, big_npy, index_rate, version, protect,
-           noise=None):
+           noise=None, keep_on_device=False):
         """One padded chunk -> float32 waveform at tgt_sr (reference :372-472).  `noise` = (noise_z, noise_src)
-        replaces the synthesizer's random draws (parity tests)."""
+        replaces the synthesizer's random draws (parity tests); `keep_on_device` returns the waveform as a device
+        tensor instead of the reference's numpy array (used by pipeline(), which post-processes on the device)."""
         feats = torch.from_numpy(np.ascontiguousarray(audio0)).float()
         if feats.dim() == 2:
             feats = feats.mean(-1)
@@ -147,7 +148,12 @@ class VC(object):
             o = net_g.infer(None, lens, pitch, pitchf, sid, noise_z=nz, noise_src=ns, phone_ct=phone_ct)[0]
         else:
             o = net_g.infer(None, lens, sid, noise_z=nz, noise_src=ns, phone_ct=phone_ct)[0]
-        audio1 = o[0, 0].data.cpu().float().numpy()
+        if keep_on_device:
+            if self._sync():
+                torch.cuda.synchronize()
+            audio1 = o[0, 0]
+        else:
+            audio1 = o[0, 0].data.cpu().float().numpy()
         t2 = ttime()
         times[0] += t1 - t0
         times[2] += t2 - t1
@@ -159,16 +165,18 @@ class VC(object):
     # ---- whole track ----------------------------------------------------------------------------------------------
     def plan(self, audio):
         """High-pass, cut search and padding (reference :513-534): -> (audio_hp float64, audio_pad, opt_ts, p_len)."""
-        audio = signal.filtfilt(bh, ah, audio)
+        audio = signal.filtfilt(bh, ah, audio)  # zero-phase IIR (float64, sequential recurrence): stays on the host
         audio_pad = np.pad(audio, (self.window // 2, self.window // 2), mode="reflect")
         opt_ts = []
         if audio_pad.shape[0] > self.t_max:
-            audio_sum = np.zeros_like(audio)
-            for i in range(self.window):
-                audio_sum += audio_pad[i: i - self.window]
-            for t in range(self.t_center, audio.shape[0], self.t_center):
-                seg = np.abs(audio_sum[t - self.t_query: t + self.t_query])
-                opt_ts.append(t - self.t_query + np.where(seg == seg.min())[0][0])
+            # 160-tap box sum in the reference's summation order + first-minimum search, on the device (bit-exact)
+            ap = torch.from_numpy(audio_pad).to(self.device)
+            audio_sum = ops.box_sum_f64(ap, audio.shape[0], self.window)
+            centers = list(range(self.t_center, audio.shape[0], self.t_center))
+            starts = [t - self.t_query for t in centers]
+            lens = [min(t + self.t_query, audio.shape[0]) - (t - self.t_query) for t in centers]
+            idx = ops.argmin_abs_f64(audio_sum, starts, lens).cpu().numpy()
+            opt_ts = [int(s0 + i) for s0, i in zip(starts, idx)]
         audio_pad = np.pad(audio, (self.t_pad, self.t_pad), mode="reflect")
         return audio, audio_pad, opt_ts, audio_pad.shape[0] // self.window
 
@@ -235,22 +243,29 @@ class VC(object):
                 pc = pcf = None
             noise = noise_fn(ci, s, e) if noise_fn is not None else None
             out = self.vc(model, net_g, sid, audio_pad[s:e], pc, pcf, times, index, big_npy, index_rate, version, protect,
-                          noise=noise)
+                          noise=noise, keep_on_device=True)
             pieces[ci] = out[self.t_pad_tgt: -self.t_pad_tgt]
         tc1 = ttime()
         pieces = adist.gather_pieces(pieces, len(bounds), self.device, group)
-        audio_opt = np.concatenate([pieces[i] for i in range(len(bounds))])
-        if rms_mix_rate != 1:
-            audio_opt = change_rms(audio, 16000, audio_opt, tgt_sr, rms_mix_rate)
+        audio_opt = torch.cat([pieces[i] for i in range(len(bounds))]).contiguous()
         if resample_sr >= 16000 and tgt_sr != resample_sr:
+            # optional output resampling (rvc_infer passes resample_sr=0): host fallback, not on the hot path
+            a = audio_opt.cpu().numpy()
+            if rms_mix_rate != 1:
+                a = change_rms(audio, 16000, a, tgt_sr, rms_mix_rate)
             from scipy.signal import resample_poly
             g = np.gcd(int(tgt_sr), int(resample_sr))
-            audio_opt = resample_poly(audio_opt, resample_sr // g, tgt_sr // g).astype(np.float32)
-        audio_max = np.abs(audio_opt).max() / 0.99
+            audio_opt = torch.from_numpy(resample_poly(a, resample_sr // g, tgt_sr // g).astype(np.float32)).to(self.device)
+        elif rms_mix_rate != 1:
+            # change_rms on the device: frame RMS envelopes (1 s frames, 0.5 s hop), linear interpolation, power mix
+            rms1 = ops.frame_rms(torch.from_numpy(np.ascontiguousarray(audio)).to(self.device), 16000 // 2 * 2, 16000 // 2)
+            rms2 = ops.frame_rms(audio_opt, tgt_sr // 2 * 2, tgt_sr // 2)
+            ops.rms_mix_(audio_opt, rms1, rms2, rms_mix_rate)
+        audio_max = float(ops.absmax(audio_opt).item()) / 0.99
         max_int16 = 32768
         if audio_max > 1:
             max_int16 /= audio_max
-        audio_opt = (audio_opt * max_int16).astype(np.int16)
+        audio_opt = ops.to_int16(audio_opt, max_int16).cpu().numpy()
         # wall-clock split of this call (host pre-processing, f0, chunk loop, join + host post-processing)
         self.last_profile = {"plan_s": t1 - tp0, "f0_s": t2 - t1, "chunks_s": tc1 - t2, "post_s": ttime() - tc1}
         return audio_opt

@@ -199,6 +199,25 @@ int aicg_mul(const float* a, const float* b, float* out, int64_t n, void* stream
 int aicg_axpbypcz(const float* a, float alpha, const float* b, float beta, const float* c, float gamma, float* out,
                   int64_t n, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * VC.pipeline pre/post-processing on the device (reference src/vc_infer_pipeline.py)
+ * ---------------------------------------------------------------------------------------------- */
+/* out[j] = sum_{i<window} x[j+i], j < n, summed in ascending i like the reference loop (:518-519); x has n+window-1 */
+int aicg_box_sum_f64(const double* x, double* out, int64_t n, int window, void* stream);
+/* per segment s: out[s] = first index of min |x[starts[s] + i]|, i < lens[s]  (np.where(a == a.min())[0][0], :524-527) */
+int aicg_argmin_abs_f64(const double* x, const int64_t* starts, const int64_t* lens, int64_t* out, int n_seg,
+                        void* stream);
+/* librosa.feature.rms(y=x, frame_length, hop_length) with center=True / reflect padding (:43-46); x is float32 or
+ * float64 (is_f64); out: 1 + n/hop_length float64 values */
+int aicg_frame_rms(const void* x, int is_f64, double* out, int64_t n, int frame_length, int hop_length, void* stream);
+/* data *= interp(rms1)^(1-rate) * max(interp(rms2), 1e-6)^(rate-1), linear interpolation to n points (:47-59) */
+int aicg_rms_mix(float* data, int64_t n, const double* rms1, int64_t m1, const double* rms2, int64_t m2, double rate,
+                 void* stream);
+/* out[0] = max |x| (:645) */
+int aicg_absmax(const float* x, int64_t n, float* out, void* stream);
+/* out = (x * scale).astype(int16), truncating (:649) */
+int aicg_to_int16(const float* x, int16_t* out, int64_t n, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -219,6 +219,11 @@ inline float atomicAdd(float* p, float v) {
     do { old = *p; nw = old + v; } while (!__atomic_compare_exchange(p, &old, &nw, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED));
     return old;
 }
+inline unsigned atomicMax(unsigned* p, unsigned v) {
+    unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
 inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 
