@@ -71,8 +71,8 @@ class VC(object):
 
     # ---- f0 ---------------------------------------------------------------------------------------------------
     def get_f0_crepe_computation(self, x, f0_min, f0_max, p_len, hop_length=160, model="full"):
-        from . import crepe
-        return crepe.mangio_crepe_f0(self, x, f0_min, f0_max, p_len, hop_length, model)
+        raise NotImplementedError("mangio-crepe (torchcrepe CREPE-full + Viterbi, SURVEY 8a a12/a13) is the next f0 method "
+                                  "to be built; use f0_method='rmvpe'")
 
     def get_f0(self, input_audio_path, x, p_len, f0_up_key, f0_method, filter_radius, crepe_hop_length, inp_f0=None):
         """-> (f0_coarse int64 (n,), f0 float64 (n,)) (reference :262-370)."""
