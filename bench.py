@@ -64,14 +64,16 @@ def one_step(mdx, vc, hub, net_g, wave44_dev, wave16, group):
     return sep, out, times, dict(vc.last_profile, mdx_s=mdx_s)
 
 
-def cpu_baseline(seconds_rvc=6.0):
+def cpu_baseline(seconds_rvc=4.0):
     """The oracle (CPU restatement of the reference, "port") timed on this box's host cores on a bounded sample:
-    one MDX window pair (denoise => 2 U-Net passes, 5.75 s of audio) + the RVC pipeline on `seconds_rvc` s."""
+    one MDX window pair (denoise => 2 U-Net passes, 5.57 s of audio) + the RVC pipeline on `seconds_rvc` s.
+    Threads: min(host cores, 16) -- torch's intra-op pool degrades badly beyond that on these layer sizes (256
+    threads measured 100x slower than 16 on the GPU box's 256-core EPYC), so that is what is used and reported."""
     from oracle import mdxnet
     from oracle import pipeline as opipe
     from synthetic import weights
     from synthetic.inputs import song_like, vocal_like
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     mcfg = weights.MDX_VOC_FT
     sd = weights.mdx_state_dict(mcfg, 1234)
@@ -90,7 +92,7 @@ def cpu_baseline(seconds_rvc=6.0):
     opipe.vc_pipeline(nets, geo, a, tgt_sr=40000)
     rvc_cost = (time.time() - t0) / seconds_rvc
     return {"value": 1.0 / (mdx_cost + rvc_cost), "unit": "x real-time", "cores": cores, "kind": "port",
-            "sample": "1 MDX window pair (5.57 s, denoise) + VC.pipeline on %.0f s; per-audio-second costs %.2f s (MDX) + %.2f s (RVC)"
+            "sample": "1 MDX window pair (5.57 s, denoise) + VC.pipeline (rmvpe) on %.0f s; CPU seconds per audio second: %.2f (MDX) + %.2f (RVC)"
                       % (seconds_rvc, mdx_cost, rvc_cost)}
 
 
