@@ -22,7 +22,7 @@ _CTYPES = {
     "const float*": ctypes.c_void_p, "float*": ctypes.c_void_p, "void*": ctypes.c_void_p,
     "const void*": ctypes.c_void_p, "const int*": ctypes.c_void_p, "int*": ctypes.c_void_p,
     "const int64_t*": ctypes.c_void_p, "int64_t*": ctypes.c_void_p, "const double*": ctypes.c_void_p,
-    "double*": ctypes.c_void_p, "const int16_t*": ctypes.c_void_p, "int16_t*": ctypes.c_void_p,
+    "double*": ctypes.c_void_p, "const int16_t*": ctypes.c_void_p, "int16_t*": ctypes.c_void_p, "uint16_t*": ctypes.c_void_p,
     "int": ctypes.c_int, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "double": ctypes.c_double,
     "const aicg_conv_desc*": ctypes.c_void_p,
 }

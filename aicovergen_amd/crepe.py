@@ -1,0 +1,110 @@
+"""CREPE f0 estimator on the gfx950 kernels: the slice of torchcrepe 0.0.20 that the reference uses for
+f0_method='mangio-crepe' / 'mangio-crepe-tiny' (reference src/vc_infer_pipeline.py:96-137, 314-321):
+torchcrepe.predict(audio, 16000, hop, 50, 1100, model, batch_size=2*hop, pad=True) -> NaN gating -> np.interp to p_len.
+
+Frames are normalised by a reduction kernel, the six k x 1 convolutions run through the implicit-GEMM MFMA kernel
+(the k=512 / stride-4 first layer as a 4-phase k=128 convolution), BatchNorm (applied after the ReLU in CREPE) is fused
+with the 2:1 max-pool, the classifier is a k=4 convolution with a sigmoid epilogue, and the per-batch softmax + Viterbi
+decode (360 states, float64, first-index argmax like numpy) runs one workgroup per 2*hop-frame batch."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+WINDOW, PITCH_BINS = 1024, 360
+BN_EPS = 0.0010000000474974513
+
+
+def _freq_to_bin(freq, ceil=False):
+    b = (1200.0 * np.log2(freq / 10.0) - 1997.3794084376191) / 20
+    return int(np.ceil(b) if ceil else np.floor(b))
+
+
+class Crepe:
+    def __init__(self, state_dict, device):
+        sd = state_dict
+        dev = torch.device(device)
+        self.device = dev
+        self.layers = []
+        for i in range(6):
+            n = "conv%d" % (i + 1)
+            w = sd[n + ".weight"].float()[..., 0]             # (Cout, Cin, k)
+            b = sd[n + ".bias"].float()
+            s = sd[n + "_BN.weight"].float() / torch.sqrt(sd[n + "_BN.running_var"].float() + BN_EPS)
+            t = sd[n + "_BN.bias"].float() - sd[n + "_BN.running_mean"].float() * s
+            if i == 0:
+                co, _, k = w.shape                              # Conv(1 -> C, k = 512, stride 4) as 4 phases x k = 128
+                w4 = w.view(co, k // 4, 4).permute(0, 2, 1).contiguous()
+                pc = ops.PackedConv(w4, b, device=dev)
+            else:
+                pc = ops.PackedConv(w, b, padding=31, padding_end=32, device=dev)
+            self.layers.append((pc, s.contiguous().to(dev), t.contiguous().to(dev)))
+        wf = sd["classifier.weight"].float()                    # (360, 4*C): feature index = h*C + c
+        c_last = wf.shape[1] // 4
+        self.fc = ops.PackedConv(wf.view(PITCH_BINS, 4, c_last).permute(0, 2, 1).contiguous(), sd["classifier.bias"].float(),
+                                 device=dev)
+
+    def __call__(self, frames):
+        """frames (B, 1024) normalised -> (B, 360) sigmoid posteriors."""
+        b = frames.shape[0]
+        xp = F.pad(frames, (254, 254))                                      # zero padding of the first conv
+        x = xp.view(b, 383, 4).transpose(1, 2).contiguous()                 # 4-phase view X[ph][q] = xpad[4q + ph]
+        for i, (pc, s, t) in enumerate(self.layers):
+            x = ops.conv(x, pc, act=ops.ACT_RELU)
+            x = ops.affine_maxpool2(x, s, t)
+        return ops.conv(x, self.fc, act=ops.ACT_SIGMOID)[:, :, 0]
+
+
+def load_crepe(model, device):
+    """torchcrepe ships its weights inside the pip package (assets/full.pth / tiny.pth)."""
+    import importlib.util
+    import os
+    spec = importlib.util.find_spec("torchcrepe")
+    if spec is None or not spec.submodule_search_locations:
+        raise RuntimeError("CREPE weights not found: torchcrepe (which bundles assets/%s.pth) is not installed; pass a "
+                           "state_dict to VC.model_crepe instead" % model)
+    path = os.path.join(list(spec.submodule_search_locations)[0], "assets", "%s.pth" % model)
+    return Crepe(torch.load(path, map_location="cpu"), device)
+
+
+def predict(net, audio, hop, fmin=50.0, fmax=1100.0, batch_size=None, dither=None, frame_batch=2048):
+    """torchcrepe.predict for a 16 kHz (N,) waveform on net.device -> (pitch float32 (n_frames,), bins int64).
+    `dither` replaces torchcrepe's random triangular dither of the bin centres (None draws it from torch's RNG)."""
+    dev = net.device
+    a = torch.as_tensor(audio).float().to(dev).view(-1)
+    total = 1 + a.numel() // hop
+    ap = F.pad(a, (WINDOW // 2, WINDOW // 2))
+    post = torch.empty((total, PITCH_BINS), dtype=torch.float32, device=dev)
+    for i in range(0, total, frame_batch):
+        n = min(frame_batch, total - i)
+        fr = ap[i * hop:].unfold(0, WINDOW, hop)[:n].contiguous()          # frame extraction (re-indexing)
+        post[i:i + n] = net(ops.frame_normalize(fr))
+    batch_size = batch_size or total
+    n_seq = (total + batch_size - 1) // batch_size
+    probs = torch.zeros((n_seq, PITCH_BINS, batch_size), dtype=torch.float32, device=dev)
+    lens = []
+    for s in range(n_seq):
+        seg = post[s * batch_size:(s + 1) * batch_size]
+        probs[s, :, :seg.shape[0]] = seg.t()
+        lens.append(seg.shape[0])
+    bins = ops.crepe_viterbi(probs, lens, _freq_to_bin(fmin), _freq_to_bin(fmax, ceil=True))
+    bins = torch.cat([bins[s, :lens[s]] for s in range(n_seq)])
+    cents = (20 * bins + 1997.3794084376191).float()
+    if dither is None:
+        u = torch.rand(2, bins.numel(), device=dev)
+        dither = (u[0] + u[1] - 1.0) * 20.0                                # triangular on (-20, 20) cents
+    cents = cents + torch.as_tensor(dither, dtype=torch.float32, device=dev)
+    return (10 * 2 ** (cents / 1200)), bins, post
+
+
+def mangio_crepe_f0(net, x, p_len, hop, dither=None):
+    """VC.get_f0_crepe_computation (reference src/vc_infer_pipeline.py:96-137)."""
+    x = x.astype(np.float32)
+    x = x / np.quantile(np.abs(x), 0.999)
+    pitch, bins, post = predict(net, x, hop, 50.0, 1100.0, batch_size=hop * 2, dither=dither)
+    p_len = p_len or x.shape[0] // hop
+    source = pitch.cpu().float().numpy()
+    source[source < 0.001] = np.nan
+    target = np.interp(np.arange(0, len(source) * p_len, len(source)) / p_len, np.arange(0, len(source)), source)
+    return np.nan_to_num(target)

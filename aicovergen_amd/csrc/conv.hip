@@ -310,8 +310,9 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
         return fail(AICG_E_SHAPE, "aicg_conv_forward: channels not divisible by groups");
     if (d->KH < 1 || d->KW < 1 || d->stride_h < 1 || d->stride_w < 1 || d->dil_h < 1 || d->dil_w < 1)
         return fail(AICG_E_SHAPE, "aicg_conv_forward: bad kernel geometry");
-    int Ho = (d->H + 2 * d->pad_h - d->dil_h * (d->KH - 1) - 1) / d->stride_h + 1;
-    int Wo = (d->W + 2 * d->pad_w - d->dil_w * (d->KW - 1) - 1) / d->stride_w + 1;
+    const int pad_h_end = d->pad_h_end < 0 ? d->pad_h : d->pad_h_end, pad_w_end = d->pad_w_end < 0 ? d->pad_w : d->pad_w_end;
+    int Ho = (d->H + d->pad_h + pad_h_end - d->dil_h * (d->KH - 1) - 1) / d->stride_h + 1;
+    int Wo = (d->W + d->pad_w + pad_w_end - d->dil_w * (d->KW - 1) - 1) / d->stride_w + 1;
     // the caller may ask for fewer outputs than the geometry yields (fairseq SamePad drops the last frame)
     if (d->Ho > Ho || d->Wo > Wo || d->Ho < 0 || d->Wo < 0)
         return fail(AICG_E_SHAPE, "aicg_conv_forward: output %dx%d exceeds geometry (%dx%d)", d->Ho, d->Wo, Ho, Wo);

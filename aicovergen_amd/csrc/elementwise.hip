@@ -254,3 +254,58 @@ extern "C" int aicg_axpbypcz(const float* a, float alpha, const float* b, float 
                        gamma, out, (long)n);
     return aicg::check_launch("axpbypcz_kernel");
 }
+
+// ---- CREPE helpers (torchcrepe 0.0.20 as called at reference src/vc_infer_pipeline.py:116-126) ----------------------
+namespace aicg {
+// frames -= mean; frames /= max(1e-10, std (unbiased)) per 1024-sample frame (torchcrepe.preprocess)
+__global__ void __launch_bounds__(256) frame_normalize_kernel(const float* __restrict__ x, float* __restrict__ out, int L) {
+    __shared__ float sh[4];
+    const float* xr = x + (long)blockIdx.x * L;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < L; i += 256) s += xr[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float mean = (sh[0] + sh[1] + sh[2] + sh[3]) / (float)L;
+    __syncthreads();
+    float v = 0.f;
+    for (int i = threadIdx.x; i < L; i += 256) { const float d = xr[i] - mean; v += d * d; }
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float sd = fmaxf(1e-10f, sqrtf((sh[0] + sh[1] + sh[2] + sh[3]) / (float)(L - 1)));
+    float* orow = out + (long)blockIdx.x * L;
+    for (int i = threadIdx.x; i < L; i += 256) orow[i] = (xr[i] - mean) / sd;
+}
+
+// eval BatchNorm (per-channel affine) followed by MaxPool (2,1)/(2,1) along the last axis: (N, C, W) -> (N, C, W/2)
+__global__ void __launch_bounds__(256) affine_maxpool2_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, float* __restrict__ out, int C,
+                                                              int Wo, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)((i / Wo) % C);
+        const float s = scale[c], t = shift[c];
+        const float a = x[2 * i] * s + t, b = x[2 * i + 1] * s + t;
+        out[i] = fmaxf(a, b);
+    }
+}
+}  // namespace aicg
+
+extern "C" int aicg_frame_normalize(const float* x, float* out, int64_t n_frames, int frame_len, void* stream) {
+    if (!x || !out) return aicg::fail(AICG_E_ARG, "aicg_frame_normalize: null pointer");
+    if (frame_len < 2) return aicg::fail(AICG_E_SHAPE, "aicg_frame_normalize: frame too short");
+    if (n_frames <= 0) return AICG_OK;
+    hipLaunchKernelGGL(aicg::frame_normalize_kernel, dim3((unsigned)n_frames), dim3(256), 0, (hipStream_t)stream, x, out, frame_len);
+    return aicg::check_launch("frame_normalize_kernel");
+}
+
+extern "C" int aicg_affine_maxpool2(const float* x, const float* scale, const float* shift, float* out, int N, int C, int W,
+                                    void* stream) {
+    if (!x || !scale || !shift || !out) return aicg::fail(AICG_E_ARG, "aicg_affine_maxpool2: null pointer");
+    if (W & 1) return aicg::fail(AICG_E_SHAPE, "aicg_affine_maxpool2: W must be even");
+    const long total = (long)N * C * (W / 2);
+    if (total == 0) return AICG_OK;
+    hipLaunchKernelGGL(aicg::affine_maxpool2_kernel, dim3(aicg::ew_grid(total)), dim3(256), 0, (hipStream_t)stream, x, scale, shift,
+                       out, C, W / 2, total);
+    return aicg::check_launch("affine_maxpool2_kernel");
+}

@@ -253,3 +253,93 @@ extern "C" int aicg_f0_coarse(const double* f0_in, double factor, double* f0_out
                        (long*)coarse, (long)n, mel_min, mel_max);
     return check_launch("f0_coarse_kernel");
 }
+
+// ---- CREPE decode: softmax over bins + Viterbi (torchcrepe.decode.viterbi -> librosa.sequence.viterbi) ------------
+// probs: (n_seq, 360, n_steps_max) fp32 sigmoid outputs with bins outside [lo, hi) already masked by the caller's
+// convention (handled here: masked bins get -inf before the softmax).  One workgroup per sequence (the reference
+// decodes each 2*hop-frame batch independently); thread j owns state j.  Arithmetic in float64 like numpy:
+//   value[0][j] = log_prob[0][j] + log(1/360 + eps);  value[t][j] = log_prob[t][j] + max_i(value[t-1][i] + log_trans[i][j])
+// with first-index argmax, eps = float32 tiny, transition = normalised max(12 - |i-j|, 0).
+namespace aicg {
+__global__ void __launch_bounds__(384) crepe_viterbi_kernel(const float* __restrict__ probs, const int* __restrict__ seq_len,
+                                                            float* __restrict__ logp, unsigned short* __restrict__ ptr,
+                                                            long* __restrict__ bins_out, int NB, int max_steps, int lo, int hi) {
+    HIP_DYNAMIC_SHARED(double, dsm)
+    double (*val)[384] = reinterpret_cast<double (*)[384]>(dsm);  // [2][384]
+    double* ltrans_band = dsm + 2 * 384;  // log_trans[i][j] for |i - j| <= 11, indexed [i][j - i + 11]; 23 of 24 used
+    const int seq = blockIdx.x, j = threadIdx.x;
+    const int T = seq_len[seq];
+    const float* pr = probs + (long)seq * NB * max_steps;
+    float* lp = logp + (long)seq * NB * max_steps;              // [t][j]
+    unsigned short* pt = ptr + (long)seq * NB * max_steps;      // [t][j]
+    const float eps32 = 1.17549435e-38f;
+    const double eps = (double)eps32;
+    // phase 1: per-frame softmax over bins (fp32, like torch.nn.functional.softmax), log(prob + eps) in fp32
+    for (int t = j; t < T; t += 384) {
+        float mx = -INFINITY;
+        for (int b = lo; b < hi; ++b) mx = fmaxf(mx, pr[(long)b * max_steps + t]);
+        float sum = 0.f;
+        for (int b = lo; b < hi; ++b) sum += expf(pr[(long)b * max_steps + t] - mx);
+        for (int b = 0; b < NB; ++b) {
+            const float p = (b >= lo && b < hi) ? expf(pr[(long)b * max_steps + t] - mx) / sum : 0.f;
+            lp[(long)t * NB + b] = logf(p + eps32);
+        }
+    }
+    // transition band of row j (rows are normalised: sum_i max(12 - |i - j|, 0))
+    if (j < NB) {
+        double rs = 0.0;
+        for (int i = 0; i < NB; ++i) { const int d = i > j ? i - j : j - i; if (d < 12) rs += (double)(12 - d); }
+        for (int d = -11; d <= 11; ++d) {
+            const int i = j + d;
+            ltrans_band[j * 24 + d + 11] = (i >= 0 && i < NB) ? log((double)(12 - (d < 0 ? -d : d)) / rs + eps) : 0.0;
+        }
+    }
+    const double lfar = log(eps);                      // log(0 + eps) for |i - j| >= 12
+    const double lpinit = log(1.0 / (double)NB + eps);
+    __syncthreads();
+    if (T <= 0) return;
+    if (j < NB) val[0][j] = (double)lp[j] + lpinit;
+    __syncthreads();
+    int cur = 0;
+    for (int t = 1; t < T; ++t) {
+        if (j < NB) {
+            // trans_out[j][i] = value[t-1][i] + log_trans[i][j]; the matrix is symmetric in |i - j| but rows are normalised
+            // per source state i, so the band entry must be taken from row i
+            double best = -INFINITY;
+            int bi = 0;
+            for (int i = 0; i < NB; ++i) {
+                const int d = j - i;  // position of j in row i
+                const double lt = (d >= -11 && d <= 11) ? ltrans_band[i * 24 + d + 11] : lfar;
+                const double v = val[cur][i] + lt;
+                if (v > best) { best = v; bi = i; }
+            }
+            pt[(long)t * NB + j] = (unsigned short)bi;
+            val[cur ^ 1][j] = (double)lp[(long)t * NB + j] + best;
+        }
+        cur ^= 1;
+        __syncthreads();
+    }
+    // state[T-1] = argmax_j value[T-1][j] (first maximum), then backtrack
+    if (j == 0) {
+        double best = -INFINITY;
+        int s = 0;
+        for (int i = 0; i < NB; ++i) if (val[cur][i] > best) { best = val[cur][i]; s = i; }
+        long* bo = bins_out + (long)seq * max_steps;
+        bo[T - 1] = s;
+        for (int t = T - 2; t >= 0; --t) { s = pt[(long)(t + 1) * NB + s]; bo[t] = s; }
+    }
+}
+}  // namespace aicg
+
+extern "C" int aicg_crepe_viterbi(const float* probs, const int* seq_len, float* logp_scratch, uint16_t* ptr_scratch,
+                                  int64_t* bins_out, int n_seq, int n_bins, int max_steps, int bin_lo, int bin_hi, void* stream) {
+    if (!probs || !seq_len || !logp_scratch || !ptr_scratch || !bins_out) return aicg::fail(AICG_E_ARG, "aicg_crepe_viterbi: null pointer");
+    if (n_bins > 384 || n_bins < 24 || bin_lo < 0 || bin_hi > n_bins || bin_lo >= bin_hi)
+        return aicg::fail(AICG_E_SHAPE, "aicg_crepe_viterbi: bad bin range");
+    if (n_seq <= 0) return AICG_OK;
+    const size_t lds = (size_t)(2 * 384 + 384 * 24) * sizeof(double);
+    (void)hipFuncSetAttribute((const void*)aicg::crepe_viterbi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(aicg::crepe_viterbi_kernel, dim3((unsigned)n_seq), dim3(384), lds, (hipStream_t)stream, probs, seq_len,
+                       logp_scratch, (unsigned short*)ptr_scratch, (long*)bins_out, n_bins, max_steps, bin_lo, bin_hi);
+    return aicg::check_launch("crepe_viterbi_kernel");
+}

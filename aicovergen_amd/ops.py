@@ -118,7 +118,7 @@ class ConvDesc(ctypes.Structure):
                [(n, ctypes.c_int64) for n in ("x_sn", "x_sc", "x_sh", "y_sn", "y_sc", "y_sh", "r_sn", "r_sc", "r_sh")] + \
                [("pre_act", ctypes.c_int32), ("pre_slope", ctypes.c_float), ("act", ctypes.c_int32),
                 ("act_slope", ctypes.c_float), ("out_scale", ctypes.c_float), ("accumulate", ctypes.c_int32),
-                ("res_before_act", ctypes.c_int32)]
+                ("res_before_act", ctypes.c_int32), ("pad_h_end", ctypes.c_int32), ("pad_w_end", ctypes.c_int32)]
 
 
 def conv_bkc(taps):
@@ -142,7 +142,8 @@ def pack_conv_weight(w, groups=1):
 class PackedConv:
     """A convolution layer ready for aicg_conv_forward: packed weights + geometry.  1-D layers use KH=1."""
 
-    def __init__(self, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, device=None):
+    def __init__(self, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, device=None, padding_end=None):
+        self.padding_end = None if padding_end is None else (0, _one(padding_end)) if weight.dim() == 3 else _pair(padding_end)
         if weight.dim() == 3:  # Conv1d (Cout, Cin_g, K)
             weight = weight.unsqueeze(2)
             stride, padding, dilation = (1, _one(stride)), (0, _one(padding)), (1, _one(dilation))
@@ -160,8 +161,9 @@ class PackedConv:
         self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
 
     def out_hw(self, h, w):
-        ho = (h + 2 * self.padding[0] - self.dilation[0] * (self.kh - 1) - 1) // self.stride[0] + 1
-        wo = (w + 2 * self.padding[1] - self.dilation[1] * (self.kw - 1) - 1) // self.stride[1] + 1
+        pe = self.padding if self.padding_end is None else self.padding_end
+        ho = (h + self.padding[0] + pe[0] - self.dilation[0] * (self.kh - 1) - 1) // self.stride[0] + 1
+        wo = (w + self.padding[1] + pe[1] - self.dilation[1] * (self.kw - 1) - 1) // self.stride[1] + 1
         return ho, wo
 
 
@@ -235,6 +237,7 @@ def conv(x, pc, res=None, out=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NON
     d.pre_act, d.pre_slope, d.act, d.act_slope = pre_act, pre_slope, act, act_slope
     d.out_scale, d.accumulate = out_scale, 1 if accumulate else 0
     d.res_before_act = 1 if res_before_act else 0
+    d.pad_h_end, d.pad_w_end = (-1, -1) if pc.padding_end is None else pc.padding_end
     prof = conv_profile
     if prof is not None and x.is_cuda:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -559,3 +562,38 @@ def to_int16(x, scale):
     _check(x)
     _lib.call("aicg_to_int16", _ptr(x), _ptr(out), x.numel(), float(scale), _stream(x))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# CREPE helpers
+# ---------------------------------------------------------------------------------------------------
+def frame_normalize(frames):
+    assert frames.is_contiguous() and frames.dim() == 2
+    out = torch.empty_like(frames)
+    _check(frames)
+    _lib.call("aicg_frame_normalize", _ptr(frames), _ptr(out), frames.shape[0], frames.shape[1], _stream(frames))
+    return out
+
+
+def affine_maxpool2(x, scale, shift):
+    """x (N, C, W) contiguous -> max over pairs of (x * scale[c] + shift[c]) -> (N, C, W/2)."""
+    assert x.is_contiguous() and x.dim() == 3
+    n, c, w = x.shape
+    out = torch.empty((n, c, w // 2), dtype=torch.float32, device=x.device)
+    _check(x, scale, shift)
+    _lib.call("aicg_affine_maxpool2", _ptr(x), _ptr(scale), _ptr(shift), _ptr(out), n, c, w, _stream(x))
+    return out
+
+
+def crepe_viterbi(probs, seq_len, bin_lo, bin_hi):
+    """probs (n_seq, 360, max_steps) fp32, seq_len list -> bins int64 (n_seq, max_steps)."""
+    probs = probs.contiguous()
+    n_seq, nb, ms = probs.shape
+    sl = torch.tensor(list(seq_len), dtype=torch.int32, device=probs.device)
+    logp = torch.empty((n_seq, ms, nb), dtype=torch.float32, device=probs.device)
+    ptr = torch.empty((n_seq, ms, nb), dtype=torch.int16, device=probs.device)
+    bins = torch.zeros((n_seq, ms), dtype=torch.int64, device=probs.device)
+    _check(probs)
+    _lib.call("aicg_crepe_viterbi", _ptr(probs), _ptr(sl), _ptr(logp), _ptr(ptr), _ptr(bins), n_seq, nb, ms, int(bin_lo),
+              int(bin_hi), _stream(probs))
+    return bins

@@ -70,9 +70,16 @@ class VC(object):
         return torch.device("cpu")
 
     # ---- f0 ---------------------------------------------------------------------------------------------------
-    def get_f0_crepe_computation(self, x, f0_min, f0_max, p_len, hop_length=160, model="full"):
-        raise NotImplementedError("mangio-crepe (torchcrepe CREPE-full + Viterbi, SURVEY 8a a12/a13) is the next f0 method "
-                                  "to be built; use f0_method='rmvpe'")
+    def get_f0_crepe_computation(self, x, f0_min, f0_max, p_len, hop_length=160, model="full", dither=None):
+        """mangio-crepe (reference :96-137).  The CREPE network is built lazily from torchcrepe's bundled weights, or
+        injected as `self.model_crepe[model]` (tests / benchmarks use seeded parameters)."""
+        from . import crepe
+        if not hasattr(self, "model_crepe"):
+            self.model_crepe = {}
+        if model not in self.model_crepe:
+            self.model_crepe[model] = crepe.load_crepe(model, self.device)
+        print("Initiating prediction with a crepe_hop_length of: " + str(hop_length))
+        return crepe.mangio_crepe_f0(self.model_crepe[model], x, p_len, hop_length, dither=dither)
 
     def get_f0(self, input_audio_path, x, p_len, f0_up_key, f0_method, filter_radius, crepe_hop_length, inp_f0=None):
         """-> (f0_coarse int64 (n,), f0 float64 (n,)) (reference :262-370)."""

@@ -99,6 +99,8 @@ typedef struct aicg_conv_desc {
     float out_scale;
     int32_t accumulate; /* nonzero: add into y instead of overwriting */
     int32_t res_before_act; /* nonzero: y = out_scale * act(acc + bias + res)  (e.g. emb_phone + emb_pitch -> lrelu) */
+    int32_t pad_h_end, pad_w_end; /* zero padding after the last row / column; -1 = same as pad_h / pad_w
+                                     (torchcrepe pads (31, 32) around its k=64 convs) */
 } aicg_conv_desc;
 
 int aicg_conv_bkc(int taps);
@@ -217,6 +219,20 @@ int aicg_rms_mix(float* data, int64_t n, const double* rms1, int64_t m1, const d
 int aicg_absmax(const float* x, int64_t n, float* out, void* stream);
 /* out = (x * scale).astype(int16), truncating (:649) */
 int aicg_to_int16(const float* x, int16_t* out, int64_t n, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * CREPE f0 (torchcrepe 0.0.20 `predict`, called at src/vc_infer_pipeline.py:116-126 for f0_method mangio-crepe)
+ * ---------------------------------------------------------------------------------------------- */
+/* torchcrepe.preprocess: per 1024-sample frame, x = (x - mean) / max(1e-10, unbiased std) */
+int aicg_frame_normalize(const float* x, float* out, int64_t n_frames, int frame_len, void* stream);
+/* eval BatchNorm2d (per-channel scale/shift, applied AFTER the ReLU in CREPE) + MaxPool (2,1): (N,C,W) -> (N,C,W/2) */
+int aicg_affine_maxpool2(const float* x, const float* scale, const float* shift, float* out, int N, int C, int W,
+                         void* stream);
+/* torchcrepe.decode.viterbi on each sequence independently: probs (n_seq, n_bins, max_steps) fp32 posteriors, bins
+ * outside [bin_lo, bin_hi) masked to -inf, softmax over bins, librosa.sequence.viterbi with the 12-bin triangular
+ * transition; bins_out (n_seq, max_steps) int64.  Scratch: logp (n_seq*max_steps*n_bins fp32), ptr (same, uint16). */
+int aicg_crepe_viterbi(const float* probs, const int* seq_len, float* logp_scratch, uint16_t* ptr_scratch,
+                       int64_t* bins_out, int n_seq, int n_bins, int max_steps, int bin_lo, int bin_hi, void* stream);
 
 #ifdef __cplusplus
 }

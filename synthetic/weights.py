@@ -300,3 +300,28 @@ def full_model_set(seed=1234):
     return dict(hubert_cfg=HUBERT_BASE, hubert_sd=hubert_state_dict(HUBERT_BASE, seed),
                 rmvpe_sd=rmvpe_state_dict(RMVPE_FULL, seed + 1),
                 synth_cfg=SYNTH_CFG_40K_V2, synth_sd=synth_state_dict(SYNTH_CFG_40K_V2, seed + 2))
+
+
+# ---------------------------------------------------------------------------------------------------
+# CREPE (torchcrepe 0.0.20 `Crepe`, pip dependency of the reference, requirements.txt:19; not vendored):
+# 6 x [pad, Conv2d (k,1), ReLU, BatchNorm2d(eps=0.0010000000474974513), MaxPool (2,1)] + Linear(in_features, 360)
+# ---------------------------------------------------------------------------------------------------
+CREPE_FULL = dict(out_channels=(1024, 128, 128, 128, 256, 512), kernels=(512, 64, 64, 64, 64, 64), stride0=4)
+CREPE_TINY = dict(out_channels=(128, 16, 16, 16, 32, 64), kernels=(512, 64, 64, 64, 64, 64), stride0=4)
+CREPE_MICRO = dict(out_channels=(16, 8, 8, 8, 8, 8), kernels=(512, 64, 64, 64, 64, 64), stride0=4)   # CPU-side tests
+
+
+def crepe_state_dict(cfg=CREPE_FULL, seed=1234):
+    g = _Gen(seed)
+    sd = {}
+    cin = 1
+    for i, (co, k) in enumerate(zip(cfg["out_channels"], cfg["kernels"])):
+        n = "conv%d" % (i + 1)
+        sd[n + ".weight"] = g.normal(co, cin, k, 1, std=math.sqrt(2.0 / (cin * k)))
+        sd[n + ".bias"] = g.normal(co, std=0.05)
+        _bn(sd, g, n + "_BN", co)
+        cin = co
+    in_features = 4 * cfg["out_channels"][-1]
+    sd["classifier.weight"] = g.normal(360, in_features, std=4.0 / math.sqrt(in_features))
+    sd["classifier.bias"] = g.normal(360, std=0.5)
+    return {kk: (v.contiguous().float() if v.is_floating_point() else v) for kk, v in sd.items()}

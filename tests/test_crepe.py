@@ -1,0 +1,99 @@
+"""CREPE (f0_method='mangio-crepe', BASELINE config 4) on the HIP kernels vs the oracle restatement of
+torchcrepe.predict + librosa's Viterbi (oracle/crepe.py; torchcrepe is not installable here: parity unpinned w.r.t. the
+pip package).  Posteriors: rel <= 1e-4; Viterbi path: bit-exact given identical posteriors."""
+import numpy as np
+import pytest
+import torch
+
+from aicovergen_amd import crepe, ops
+from conftest import rel_rms
+from oracle import crepe as ocr
+from synthetic import weights
+from synthetic.inputs import vocal_like
+
+
+def _dither(n, seed=0):
+    rng = np.random.default_rng(seed)
+    return ((rng.random(n) + rng.random(n) - 1) * 20).astype(np.float32)
+
+
+def test_crepe_micro_matches_oracle(dev):
+    cfg = weights.CREPE_MICRO
+    sd = weights.crepe_state_dict(cfg, 1234)
+    net = crepe.Crepe(sd, dev.device)
+    audio = vocal_like(1.5, 16000, 3)
+    hop = 128
+    x = (audio / np.quantile(np.abs(audio), 0.999)).astype(np.float32)
+    total = 1 + len(x) // hop
+    d = _dither(total)
+    pitch, bins, post = crepe.predict(net, x, hop, batch_size=2 * hop, dither=d)
+    op, ob, opost = ocr.predict(sd, x, hop, batch_size=2 * hop, dither=d)
+    assert post.shape == (total, 360)
+    assert rel_rms(post, torch.from_numpy(opost)) < 1e-4
+    assert (bins.cpu().numpy() == ob).mean() > 0.98
+    f0 = crepe.mangio_crepe_f0(net, audio, 150, hop, dither=d)
+    of0, _, _ = ocr.mangio_crepe_f0(sd, audio, 150, hop, dither=d)
+    assert f0.shape == of0.shape == (150,)
+    assert np.allclose(f0, of0, rtol=1e-4, atol=1e-3) or (bins.cpu().numpy() != ob).any()
+
+
+def test_crepe_frame_normalize_and_pool(dev):
+    torch.manual_seed(0)
+    fr = torch.randn(37, 1024) * 3 + 0.5
+    fr[5] = 0.25  # constant frame: std clamps at 1e-10
+    want = fr - fr.mean(1, keepdim=True)
+    want = want / torch.max(torch.tensor(1e-10), fr.std(1, keepdim=True))
+    got = ops.frame_normalize(dev.t(fr))
+    assert rel_rms(got[torch.arange(37) != 5], want[torch.arange(37) != 5]) < 1e-5
+    x = torch.randn(3, 5, 64)
+    s, t = torch.randn(5), torch.randn(5)
+    ref = torch.nn.functional.max_pool1d(x * s.view(1, -1, 1) + t.view(1, -1, 1), 2)
+    assert rel_rms(ops.affine_maxpool2(dev.t(x), dev.t(s), dev.t(t)), ref) < 1e-6
+
+
+def test_viterbi_bit_exact_on_wandering_posteriors(dev):
+    """Random-walk pitch tracks with noise, octave-jump distractors, ties and a short last batch: the decoded state
+    path must equal librosa's Viterbi (as restated in the oracle) exactly."""
+    rng = np.random.default_rng(5)
+    hop2 = 64 if not dev.big else 256
+    total = hop2 * 3 + 17
+    centre = 100 + np.cumsum(rng.integers(-6, 7, total))
+    centre = np.clip(centre, 5, 350)
+    post = rng.random((total, 360)).astype(np.float32) * 0.3
+    for t in range(total):
+        post[t, max(0, centre[t] - 2): centre[t] + 3] += 0.6
+        if t % 11 == 0:
+            post[t, (centre[t] + 60) % 360] += 0.7   # distractor the transition prior should reject
+    post[7, :] = 0.5                                  # a frame of exact ties
+    lo, hi = ocr.frequency_to_bins(50.0), ocr.frequency_to_bins(1100.0, ceil=True)
+    n_seq = (total + hop2 - 1) // hop2
+    P = torch.zeros(n_seq, 360, hop2)
+    lens, want = [], []
+    for s in range(n_seq):
+        seg = torch.from_numpy(post[s * hop2:(s + 1) * hop2])
+        P[s, :, :seg.shape[0]] = seg.t()
+        lens.append(seg.shape[0])
+        logits = seg.t().clone()
+        logits[:lo] = -float("inf")
+        logits[hi:] = -float("inf")
+        want.append(ocr.viterbi_path(torch.softmax(logits, 0).numpy()))
+    got = ops.crepe_viterbi(dev.t(P), lens, lo, hi).cpu()
+    got = np.concatenate([got[s, :lens[s]].numpy() for s in range(n_seq)])
+    assert np.array_equal(got, np.concatenate(want))
+
+
+@pytest.mark.gpu
+def test_crepe_full_matches_oracle():
+    """CREPE-full sized network (22 M parameters), 1 s of audio at hop 128."""
+    import conftest
+    conftest._bind("hip")
+    sd = weights.crepe_state_dict(weights.CREPE_FULL, 1234)
+    net = crepe.Crepe(sd, "cuda:0")
+    audio = vocal_like(1.0, 16000, 4)
+    x = (audio / np.quantile(np.abs(audio), 0.999)).astype(np.float32)
+    hop = 128
+    d = _dither(1 + len(x) // hop)
+    pitch, bins, post = crepe.predict(net, x, hop, batch_size=2 * hop, dither=d)
+    op, ob, opost = ocr.predict(sd, x, hop, batch_size=2 * hop, dither=d)
+    assert rel_rms(post, torch.from_numpy(opost)) < 1e-4
+    assert (bins.cpu().numpy() == ob).mean() > 0.98
