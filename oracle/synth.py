@@ -134,21 +134,22 @@ def generator_nsf(sd, cfg, x, f0, g, noise):
     upp = 1
     for u in up_r:
         upp *= u
-    har = sine_source(sd, f0, upp, float(sr), noise)
+    har = sine_source(sd, f0, upp, float(sr), noise) if f0 is not None else None  # _nono models: plain Generator (:253-272)
     x = F.conv1d(x, sd["dec.conv_pre.weight"], sd["dec.conv_pre.bias"], padding=3)
     x = x + F.conv1d(g, sd["dec.cond.weight"], sd["dec.cond.bias"])
     nk = len(rb_k)
     for i, (u, k) in enumerate(zip(up_r, up_k)):
         x = F.leaky_relu(x, LRELU_SLOPE)
         x = F.conv_transpose1d(x, wn_weight(sd, "dec.ups.%d" % i), sd["dec.ups.%d.bias" % i], stride=u, padding=(k - u) // 2)
-        if i + 1 < len(up_r):
-            s = 1
-            for uu in up_r[i + 1:]:
-                s *= uu
-            xs = F.conv1d(har, sd["dec.noise_convs.%d.weight" % i], sd["dec.noise_convs.%d.bias" % i], stride=s, padding=s // 2)
-        else:
-            xs = F.conv1d(har, sd["dec.noise_convs.%d.weight" % i], sd["dec.noise_convs.%d.bias" % i])
-        x = x + xs
+        if har is not None:
+            if i + 1 < len(up_r):
+                s = 1
+                for uu in up_r[i + 1:]:
+                    s *= uu
+                xs = F.conv1d(har, sd["dec.noise_convs.%d.weight" % i], sd["dec.noise_convs.%d.bias" % i], stride=s, padding=s // 2)
+            else:
+                xs = F.conv1d(har, sd["dec.noise_convs.%d.weight" % i], sd["dec.noise_convs.%d.bias" % i])
+            x = x + xs
         acc = None
         for j in range(nk):
             r = "dec.resblocks.%d." % (i * nk + j)

@@ -45,7 +45,7 @@ def _wn_conv(sd, g, name, cout, cin, k, gain=1.0, transposed=False):
     sd[name + ".bias"] = g.normal(cout, std=0.05)
 
 
-def synth_state_dict(cfg=SYNTH_CFG_40K_V2, seed=1234, phone_dim=768):
+def synth_state_dict(cfg=SYNTH_CFG_40K_V2, seed=1234, phone_dim=768, f0=True):
     """state_dict of SynthesizerTrnMs768NSFsid(*cfg) after `del net_g.enc_q` (reference src/rvc.py:129-134)."""
     (_, _, inter, hidden, filt, heads, layers, ksize, _, _, rb_k, rb_d, up_r, up_init, up_k, spk, gin, sr) = cfg
     g = _Gen(seed)
@@ -103,6 +103,9 @@ def synth_state_dict(cfg=SYNTH_CFG_40K_V2, seed=1234, phone_dim=768):
         # the reference zero-initialises `post` (modules.py:437-438); random here so the flow is not an identity
         _conv(sd, g, p + "post", half, hidden, 1, gain=0.5)
     sd["emb_g.weight"] = g.normal(spk, gin, std=0.5)
+    if not f0:  # SynthesizerTrnMs*_nono: no pitch embedding, plain Generator without the NSF source
+        sd = {k: v for k, v in sd.items() if not (k.startswith("enc_p.emb_pitch") or k.startswith("dec.noise_convs")
+                                                   or k.startswith("dec.m_source"))}
     return {k: v.contiguous().float() for k, v in sd.items()}
 
 

@@ -35,21 +35,28 @@ def injected_noise(draws):
         torch.randn_like, torch.rand = orig_randn_like, orig_rand
 
 
-def make_synth(name, cfg, T, seed):
+def make_synth(name, cfg, T, seed, variant="768f0"):
     sys.path.insert(0, REF)
-    from infer_pack.models import SynthesizerTrnMs768NSFsid
+    from infer_pack import models as ref_models
     from oracle import weights
     from oracle.inputs import synth_inputs
-    sd = weights.synth_state_dict(cfg, seed)
-    net = SynthesizerTrnMs768NSFsid(*cfg, is_half=False)
+    phone_dim, f0_on = (256 if variant.startswith("256") else 768), variant.endswith("f0")
+    sd = weights.synth_state_dict(cfg, seed, phone_dim=phone_dim, f0=f0_on)
+    cls = {"768f0": "SynthesizerTrnMs768NSFsid", "256f0": "SynthesizerTrnMs256NSFsid", "768nono": "SynthesizerTrnMs768NSFsid_nono",
+           "256nono": "SynthesizerTrnMs256NSFsid_nono"}[variant]
+    net = getattr(ref_models, cls)(*cfg, is_half=False)
     del net.enc_q
     missing = net.load_state_dict(sd, strict=False)
     assert not missing.missing_keys and not missing.unexpected_keys, missing
     net.eval()
     phone, pitch, f0, noise_z, noise_src = synth_inputs(cfg, T, seed + 1)
+    phone = phone[:, :, :phone_dim].contiguous()
     sid = torch.tensor([1])
     with torch.no_grad(), injected_noise([noise_z, noise_src.unsqueeze(-1)]):
-        o, _, (z, z_p, m_p, logs_p) = net.infer(phone, torch.tensor([T]), pitch, f0, sid)
+        if f0_on:
+            o, _, (z, z_p, m_p, logs_p) = net.infer(phone, torch.tensor([T]), pitch, f0, sid)
+        else:
+            o, _, (z, z_p, m_p, logs_p) = net.infer(phone, torch.tensor([T]), sid)
     np.savez_compressed(os.path.join(HERE, name + ".npz"), cfg_T=np.array([T]), seed=np.array([seed]),
                         audio=o[0, 0].numpy(), z=z[0].numpy(), m_p=m_p[0].numpy(), logs_p=logs_p[0].numpy())
     print(name, "audio", tuple(o.shape), float(o.abs().max()), float(o.pow(2).mean().sqrt()))
@@ -184,6 +191,8 @@ if __name__ == "__main__":
     from oracle import weights
     make_synth("synth_tiny_T24", weights.SYNTH_CFG_TINY, 24, 1234)
     make_synth("synth_40k_T16", weights.SYNTH_CFG_40K_V2, 16, 1234)
+    make_synth("synth_tiny_v1_T24", weights.SYNTH_CFG_TINY, 24, 1234, variant="256f0")
+    make_synth("synth_tiny_nono_T24", weights.SYNTH_CFG_TINY, 24, 1234, variant="768nono")
     make_hubert("hubert_tiny_1s", weights.HUBERT_TINY, 1.0, 1234)
     make_hubert("hubert_base_1s", weights.HUBERT_BASE, 1.0, 1234)
     make_rmvpe("rmvpe_tiny_1s", weights.RMVPE_TINY, 1.0, 1234)

@@ -78,3 +78,26 @@ def test_synth_default_noise_path_runs(dev):
     phone, pitch, f0, _, _ = synth_inputs(cfg, T, 2)
     o, _, _ = net.infer(phone, torch.tensor([T]), pitch, f0, torch.tensor([0]))
     assert o.shape == (1, 1, T * 400) and torch.isfinite(o).all()
+
+
+@pytest.mark.parametrize("name,variant", [("synth_tiny_v1_T24", "256f0"), ("synth_tiny_nono_T24", "768nono")])
+def test_synth_variants_vs_reference_golden(dev, name, variant):
+    """v1 (256-d phone features) and _nono (no f0: plain HiFi-GAN Generator) classes, SURVEY 8f item 4."""
+    from aicovergen_amd.infer_pack import models as M
+    cfg, T = weights.SYNTH_CFG_TINY, 24
+    phone_dim, f0_on = (256 if variant.startswith("256") else 768), variant.endswith("f0")
+    gold = np.load(os.path.join(GOLD, name + ".npz"))
+    sd = weights.synth_state_dict(cfg, 1234, phone_dim=phone_dim, f0=f0_on)
+    cls = {"256f0": M.SynthesizerTrnMs256NSFsid, "768nono": M.SynthesizerTrnMs768NSFsid_nono}[variant]
+    net = cls(*cfg, is_half=False)
+    del net.enc_q
+    net.load_state_dict(sd, strict=False)
+    net.eval().to(dev.device)
+    phone, pitch, f0, nz, ns = synth_inputs(cfg, T, 1235)
+    phone = phone[:, :, :phone_dim].contiguous()
+    if f0_on:
+        o, _, (z, _, _, _) = net.infer(phone, torch.tensor([T]), pitch, f0, torch.tensor([1]), noise_z=nz, noise_src=ns)
+    else:
+        o, _, (z, _, _, _) = net.infer(phone, torch.tensor([T]), torch.tensor([1]), noise_z=nz)
+    assert rel_rms(z[0], torch.from_numpy(gold["z"])) < 1e-4
+    assert rel_rms(o[0, 0], torch.from_numpy(gold["audio"])) < 1e-4
