@@ -90,11 +90,13 @@ __global__ void __launch_bounds__(3 * HD / 2) gru_kernel(const float* __restrict
             a0 = fmaf(w0[k], hk, a0);
             a1 = fmaf(w1[k], hk, a1);
         }
+        const float* wlp = wl;
+        asm volatile("" : "+v"(wlp));  // keep LICM from hoisting the LDS-resident weights into registers
 #pragma unroll 4
         for (int k = 0; k < KL; ++k) {
             const float hk = h[KR + k];
-            a0 = fmaf(wl[k * 3 * HD + j0], hk, a0);
-            a1 = fmaf(wl[k * 3 * HD + j1], hk, a1);
+            a0 = fmaf(wlp[k * 3 * HD + j0], hk, a0);
+            a1 = fmaf(wlp[k * 3 * HD + j1], hk, a1);
         }
 #pragma unroll 4
         for (int k = KR + KL; k < HD; ++k) {
@@ -114,6 +116,111 @@ __global__ void __launch_bounds__(3 * HD / 2) gru_kernel(const float* __restrict
             od[(long)j0 * T + t] = hn;
         }
         __syncthreads();
+    }
+}
+
+// ---- two-workgroup GRU: all of W_hh on chip ------------------------------------------------------------------------
+// Each direction is split over two workgroups (hidden units [0, HD/2) and [HD/2, HD)); a workgroup keeps the 3*HD/2
+// gate rows of its units entirely on chip (KR columns of each row in registers, HD-KR in LDS), so a step costs one
+// dot product plus one exchange of HD/2 new h values with the partner.  The exchange follows the tagged-granule
+// recipe of the CDNA guide (G16 / R2): one 8-byte {tag = step+1, value} agent-scope store per unit, polled with
+// relaxed agent-scope loads; two parity slots because the partner may run one step ahead.  The four workgroups of a
+// launch are co-resident by construction (grid = 4 on a 256-CU device); spins are bounded and report through `err`.
+template <int HD, int KR>
+__global__ void __launch_bounds__(3 * HD / 2) gru2_kernel(const float* __restrict__ gi, const float* __restrict__ whh_t,
+                                                          const float* __restrict__ bhh, float* __restrict__ out, long T,
+                                                          unsigned long long* xbuf, int* err) {
+    constexpr int HH = HD / 2;      // units per workgroup
+    constexpr int NT = 3 * HH;      // threads = gate rows per workgroup
+    constexpr int KL = HD - KR;
+    constexpr int PW = (HH + 63) / 64 * 64;  // first thread of the polling group: wave-aligned
+    static_assert(PW + HH <= NT, "polling group must fit the workgroup");
+    HIP_DYNAMIC_SHARED(float, smem)
+    float* h = smem;                // HD
+    float* gh = smem + HD;          // NT
+    float* wl = smem + HD + NT;     // KL x NT
+    const int dir = blockIdx.x >> 1, part = blockIdx.x & 1;
+    const int t_ = threadIdx.x;
+    const int gate = t_ / HH, u = t_ - gate * HH;
+    const int row = gate * HD + part * HH + u;          // row of W_hh (3*HD x HD), [r ; z ; n]
+    const float* W = whh_t + (long)dir * HD * 3 * HD;   // k-major: W[k * 3*HD + row]
+    const float brow = bhh[dir * 3 * HD + row];
+    const float* gid = gi + (long)dir * 3 * HD * T;
+    float* od = out + (long)dir * HD * T;
+    unsigned long long* mine = xbuf + ((long)(dir * 2 + part) * 2) * HH;        // [parity][HH]
+    unsigned long long* theirs = xbuf + ((long)(dir * 2 + (1 - part)) * 2) * HH;
+    float wr[KR];
+#pragma unroll
+    for (int kb = 0; kb < KR; kb += 16) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wr[kb + q] = W[(long)(kb + q) * 3 * HD + row];
+        asm volatile("" ::: "memory");  // 16 loads (and their 64-bit addresses) in flight at a time, not KR
+    }
+#pragma unroll 4
+    for (int k = 0; k < KL; ++k) wl[k * NT + t_] = W[(long)(KR + k) * 3 * HD + row];
+    if (t_ < HD) h[t_] = 0.f;
+    __syncthreads();
+    const int my_unit = part * HH + u;                  // valid for t_ < HH
+    for (long s = 0; s < T; ++s) {
+        const long t = dir == 0 ? s : T - 1 - s;
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+        if (t_ < HH) {
+            g0 = gid[(long)my_unit * T + t];
+            g1 = gid[(long)(HD + my_unit) * T + t];
+            g2 = gid[(long)(2 * HD + my_unit) * T + t];
+        }
+        float a0 = brow;
+#pragma unroll
+        for (int kb = 0; kb < KR; kb += 16) {
+            // h is read 16 values (4 x ds_read_b128 broadcasts) at a time; the compiler barrier keeps it from hoisting
+            // all KR reads above the FMAs, which would evict the weights from the register file
+            float hv[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) hv[q] = h[kb + q];
+            float c0 = 0.f, c1 = 0.f;  // two short chains per chunk, folded before the next chunk: the scheduler cannot
+#pragma unroll                             // postpone one chain (and keep its 8 h values per chunk alive) past the loop
+            for (int q = 0; q < 16; q += 2) {
+                c0 = fmaf(wr[kb + q], hv[q], c0);
+                c1 = fmaf(wr[kb + q + 1], hv[q + 1], c1);
+            }
+            a0 += c0 + c1;
+            asm volatile("" : "+v"(a0));
+        }
+        // opaque copy of the LDS weight pointer: without it LICM hoists these loop-invariant LDS reads out of the
+        // step loop into registers and the register-resident part of the row gets spilled to scratch instead
+        const float* wlp = wl + t_;
+        asm volatile("" : "+v"(wlp));
+#pragma unroll 4
+        for (int k = 0; k < KL; ++k) a0 = fmaf(wlp[k * NT], h[KR + k], a0);
+        gh[t_] = a0;
+        __syncthreads();
+        const int par = (int)(s & 1);
+        if (t_ < HH) {
+            const float r = 1.f / (1.f + expf(-(g0 + gh[u])));
+            const float z = 1.f / (1.f + expf(-(g1 + gh[HH + u])));
+            const float n = tanhf(g2 + r * gh[2 * HH + u]);
+            const float hn = (1.f - z) * n + z * h[my_unit];
+            h[my_unit] = hn;
+            od[(long)my_unit * T + t] = hn;
+            const unsigned long long gran = ((unsigned long long)(unsigned)(s + 1) << 32) | (unsigned)__float_as_int(hn);
+            __hip_atomic_store(mine + par * HH + u, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (t_ >= PW && t_ < PW + HH) {
+            // a different WAVE than the publishers (a wave that polled first while its own lanes still had to publish
+            // would deadlock against the partner doing the same): fetch the partner's new h values for this step
+            const int v = t_ - PW;
+            unsigned long long gran = 0;
+            const unsigned want = (unsigned)(s + 1);
+            int spins = 0;
+            for (;;) {
+                gran = __hip_atomic_load(theirs + par * HH + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(gran >> 32) == want) break;
+                if (++spins > (1 << 22)) { *err = 1; break; }  // bounded: never hang the device
+                __builtin_amdgcn_s_sleep(1);
+            }
+            h[(1 - part) * HH + v] = __int_as_float((int)(unsigned)gran);
+        }
+        __syncthreads();
+        if (*((volatile int*)err)) return;
     }
 }
 
@@ -233,6 +340,32 @@ extern "C" int aicg_gru_bidir(const float* gi, const float* whh_t, const float* 
         return fail(AICG_E_SHAPE, "aicg_gru_bidir: hidden size %d not instantiated (256, 64)", hidden);
     }
     return check_launch("gru_kernel");
+}
+
+extern "C" int aicg_gru_bidir_2wg(const float* gi, const float* whh_t, const float* bhh, float* out, int hidden, int64_t T,
+                                  void* xchg_scratch, void* stream) {
+    // xchg_scratch: 2 dirs x 2 parts x 2 parities x hidden/2 granules of 8 bytes (= 32*hidden bytes) + an int error word
+    if (!gi || !whh_t || !bhh || !out || !xchg_scratch) return fail(AICG_E_ARG, "aicg_gru_bidir_2wg: null pointer");
+    if (T == 0) return AICG_OK;
+    const size_t xbytes = (size_t)2 * 2 * 2 * (hidden / 2) * 8;
+    (void)hipMemsetAsync(xchg_scratch, 0, xbytes + 64, (hipStream_t)stream);
+    unsigned long long* xb = (unsigned long long*)xchg_scratch;
+    int* err = (int*)((char*)xchg_scratch + xbytes);
+    if (hidden == 256) {
+        constexpr int KR = 208;
+        const size_t lds = (size_t)(256 + 384 + (256 - KR) * 384) * sizeof(float);
+        auto kern = gru2_kernel<256, KR>;
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3(4), dim3(384), lds, (hipStream_t)stream, gi, whh_t, bhh, out, (long)T, xb, err);
+    } else if (hidden == 64) {
+        constexpr int KR = 48;
+        const size_t lds = (size_t)(64 + 96 + (64 - KR) * 96) * sizeof(float);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gru2_kernel<64, KR>), dim3(4), dim3(96), lds, (hipStream_t)stream, gi, whh_t, bhh, out,
+                           (long)T, xb, err);
+    } else {
+        return fail(AICG_E_SHAPE, "aicg_gru_bidir_2wg: hidden size %d not instantiated (256, 64)", hidden);
+    }
+    return check_launch("gru2_kernel");
 }
 
 extern "C" int aicg_salience_decode(const float* salience, double* cents, double* f0, int* center, int64_t T, int n_bins,

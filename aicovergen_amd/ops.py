@@ -2,6 +2,7 @@
 functions validate shapes, allocate outputs with torch, and hand raw device pointers + the current HIP
 stream to libaicg_hip.so."""
 import math
+import os
 
 import numpy as np
 import torch
@@ -433,12 +434,22 @@ def avgpool2x2(x):
     return out
 
 
-def gru_bidir(gi, whh_t, bhh, hidden):
-    """gi: (6*hidden, T) channel-major input projections -> (2*hidden, T)."""
+GRU_TWO_WORKGROUPS = os.environ.get("AICG_GRU_2WG", "1") != "0"
+
+
+def gru_bidir(gi, whh_t, bhh, hidden, two_workgroups=None):
+    """gi: (6*hidden, T) channel-major input projections -> (2*hidden, T).  Default: the two-workgroup-per-direction
+    kernel (all of W_hh on chip); `two_workgroups=False` (or AICG_GRU_2WG=0) selects the single-workgroup kernel."""
     assert gi.is_contiguous() and gi.shape[0] == 6 * hidden
     t = gi.shape[1]
     out = torch.empty((2 * hidden, t), dtype=torch.float32, device=gi.device)
     _check(gi, whh_t, bhh)
+    if GRU_TWO_WORKGROUPS if two_workgroups is None else two_workgroups:
+        scratch = torch.empty(32 * hidden + 64, dtype=torch.uint8, device=gi.device)
+        _lib.call("aicg_gru_bidir_2wg", _ptr(gi), _ptr(whh_t), _ptr(bhh), _ptr(out), hidden, t, _ptr(scratch), _stream(gi))
+        if int(scratch[32 * hidden: 32 * hidden + 4].view(torch.int32).item()) != 0:
+            raise RuntimeError("aicg_gru_bidir_2wg: partner workgroup exchange timed out")
+        return out
     _lib.call("aicg_gru_bidir", _ptr(gi), _ptr(whh_t), _ptr(bhh), _ptr(out), hidden, t, _stream(gi))
     return out
 

@@ -176,6 +176,11 @@ int aicg_avgpool2x2(const float* x, float* out, int N, int C, int H, int W, int6
  * bhh: (2*3*hidden); out: (2*hidden, T) = [forward h ; reverse h]. */
 int aicg_gru_bidir(const float* gi, const float* whh_t, const float* bhh, float* out, int hidden, int64_t T,
                    void* stream);
+/* Same recurrence with each direction split over two co-resident workgroups that keep all of W_hh on chip and exchange
+ * the new hidden state every step through tagged 8-byte granules (agent-scope stores / relaxed polls).
+ * xchg_scratch: 32 * hidden + 64 bytes of device memory (zeroed by the call); the last int is set to 1 on a spin timeout. */
+int aicg_gru_bidir_2wg(const float* gi, const float* whh_t, const float* bhh, float* out, int hidden, int64_t T,
+                       void* xchg_scratch, void* stream);
 /* RMVPE.decode / to_local_average_cents (src/rmvpe.py:359-364,385-409).  salience: (T, n_bins) row-major fp32;
  * cents, f0: (T) float64 (bit-equal to the numpy reference given identical salience); center: (T) argmax or NULL. */
 int aicg_salience_decode(const float* salience, double* cents, double* f0, int* center, int64_t T, int n_bins,

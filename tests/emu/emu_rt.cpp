@@ -101,6 +101,16 @@ static void yield_wave() {
     die("deadlock: lane waits at a wave collective but no other lane of the wave is alive");
 }
 
+void yield_any() {
+    Block* b = tl_blk;
+    int i = cur->flat;
+    for (int s = 1; s < b->n; ++s) {
+        Fiber* f = &b->fib[(i + s) % b->n];
+        if (!f->done && f != cur) { switch_to(f); return; }
+    }
+    std::this_thread::yield();  // alone in the workgroup: let the other workgroups' OS threads run
+}
+
 void block_barrier() {
     Block* b = tl_blk;
     b->arrived++;

@@ -81,6 +81,7 @@ int lane_id();
 // exchange buffers of the current wave (64 slots of 16 bytes)
 void* wave_slot(int lane);
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
+void yield_any();  // let another work-item of the workgroup run (used by spin loops)
 }  // namespace emu
 
 #define threadIdx (::emu::cur_tid())
@@ -195,6 +196,12 @@ inline emu_f32x4 emu_mfma_f32_16x16x4f32(float a, float b, emu_f32x4 c, int, int
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 emu_mfma_f32_32x32x2f32
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 emu_mfma_f32_16x16x4f32
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_s_sleep(x) ::emu::yield_any()
+// agent-scope atomics on global memory: workgroups run on different OS threads in the emulator
+#define __HIP_MEMORY_SCOPE_AGENT 3
+#define __hip_atomic_load(p, order, scope) __atomic_load_n(p, __ATOMIC_SEQ_CST)
+#define __hip_atomic_store(p, v, order, scope) __atomic_store_n(p, v, __ATOMIC_SEQ_CST)
+#define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_s_barrier() ::emu::block_barrier()
 

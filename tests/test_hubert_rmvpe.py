@@ -129,3 +129,27 @@ def test_rmvpe_full_matches_oracle():
     assert agree.mean() > 0.98, "salience argmax agreement %.3f" % agree.mean()
     f0 = r.infer_from_audio(audio, 0.03)
     assert np.abs(f0 - of0)[agree].max() / max(1.0, of0.max()) < 1e-3
+
+
+@pytest.mark.parametrize("hidden,T", [(64, 50), (256, 33)])
+def test_gru_kernels_match_torch(dev, hidden, T):
+    """Both recurrence kernels (single workgroup per direction; two co-resident workgroups exchanging h through tagged
+    granules) vs torch.nn.GRU semantics written out in oracle/rmvpe.py::bigru."""
+    torch.manual_seed(hidden)
+    if dev.big:
+        T = T * 40 + 3
+    x = torch.randn(1, T, 384)
+    sd = {}
+    for suf in ("", "_reverse"):
+        sd["fc.0.gru.weight_ih_l0" + suf] = torch.randn(3 * hidden, 384) / hidden ** 0.5
+        sd["fc.0.gru.weight_hh_l0" + suf] = torch.randn(3 * hidden, hidden) / hidden ** 0.5
+        sd["fc.0.gru.bias_ih_l0" + suf] = torch.randn(3 * hidden) * 0.1
+        sd["fc.0.gru.bias_hh_l0" + suf] = torch.randn(3 * hidden) * 0.1
+    ref = orm.bigru(sd, x)[0].t()                                     # (2*hidden, T)
+    gi = torch.cat([torch.nn.functional.linear(x[0], sd["fc.0.gru.weight_ih_l0" + s], sd["fc.0.gru.bias_ih_l0" + s]).t()
+                    for s in ("", "_reverse")], 0).contiguous()
+    whh_t = torch.stack([sd["fc.0.gru.weight_hh_l0"].t().contiguous(), sd["fc.0.gru.weight_hh_l0_reverse"].t().contiguous()])
+    bhh = torch.cat([sd["fc.0.gru.bias_hh_l0"], sd["fc.0.gru.bias_hh_l0_reverse"]])
+    for two in (False, True):
+        got = ops.gru_bidir(dev.t(gi), dev.t(whh_t.contiguous()), dev.t(bhh), hidden, two_workgroups=two)
+        assert rel_rms(got, ref) < 1e-5, "two_workgroups=%s" % two
