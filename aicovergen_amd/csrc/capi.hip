@@ -24,3 +24,30 @@ int fail(int code, const char* fmt, ...) {
 
 extern "C" const char* aicg_last_error(void) { return aicg::g_err; }
 extern "C" int aicg_abi_version(void) { return 1; }
+
+// Diagnostic: issue-bound fp32 MFMA loop (no memory traffic) to calibrate the attainable v_mfma_f32_32x32x2_f32 rate
+// of the device the benchmarks run on (clock under load is power-dependent).  Returns nothing useful in `out` beyond
+// keeping the accumulators alive; time it from the host.
+namespace aicg {
+typedef float pf32x16 __attribute__((ext_vector_type(16)));
+__global__ void __launch_bounds__(256) mfma_probe_kernel(float* out, int iters, float seed) {
+    pf32x16 a0, a1, a2, a3;
+    for (int r = 0; r < 16; ++r) { a0[r] = seed; a1[r] = seed + 1.f; a2[r] = seed + 2.f; a3[r] = seed + 3.f; }
+    float x = seed * (float)(threadIdx.x & 7) + 0.5f, y = 0.25f + seed;
+    for (int i = 0; i < iters; ++i) {
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, x, a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, y, a3, 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int r = 0; r < 16; ++r) s += a0[r] + a1[r] + a2[r] + a3[r];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+}  // namespace aicg
+
+extern "C" int aicg_mfma_probe(float* out, int n_blocks, int iters, float seed, void* stream) {
+    if (!out) return aicg::fail(AICG_E_ARG, "aicg_mfma_probe: null pointer");
+    hipLaunchKernelGGL(aicg::mfma_probe_kernel, dim3((unsigned)n_blocks), dim3(256), 0, (hipStream_t)stream, out, iters, seed);
+    return aicg::check_launch("mfma_probe_kernel");
+}

@@ -17,6 +17,8 @@
 // A[k = l>>5][m = l&31] and B[k = l>>5][n = l&31]: both are unit-stride, conflict-free ds_read_b32.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace aicg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -50,11 +52,12 @@ static constexpr int KSTAGE = 64;  // max K rows of packed weights staged per ba
 //   written to LDS after the next barrier.  Inside the MFMA loop the A/B fragments of step i+1 are read from LDS
 //   before the MFMAs of step i issue.
 template <int BM, int BN, int WM, int WN, int XR>
-__global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs p) {
+__global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 4)) conv_mfma_kernel(ConvArgs p) {
+    constexpr int NT = 64 * WM * WN;                   // 4 or 8 waves per workgroup
     constexpr int TM = BM / (32 * WM);
     constexpr int TN = BN / (32 * WN);
-    constexpr int WR = (KSTAGE * BM / 4 + 255) / 256;  // float4 weight loads per thread per stage
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int WR = (KSTAGE * BM / 4 + NT - 1) / NT;  // float4 weight loads per thread per stage
+    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per workgroup");
     HIP_DYNAMIC_SHARED(float, smem)
     float* xs = smem;
     float* ws = smem + p.xs_elems;
@@ -106,7 +109,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs p) {
         const float* wrow0 = wg + ((long)tap0 * p.Cin_pad + (long)c * p.BKC) * p.Mpad;
 #pragma unroll
         for (int e = 0; e < WR; ++e) {
-            const int idx4 = tid + e * 256;
+            const int idx4 = tid + e * NT;
             const int r = idx4 / (BM / 4);
             const int c4 = idx4 - r * (BM / 4);
             const int mcol = m_base + c4 * 4;
@@ -120,7 +123,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs p) {
         if (tap0 == 0) {  // a new channel chunk: its input patch (halo included)
 #pragma unroll
             for (int e = 0; e < XR; ++e) {
-                const int idx = tid + e * 256;
+                const int idx = tid + e * NT;
                 const int ci = (int)__umulhi((unsigned)idx, p.div_chs);
                 const int rem = idx - ci * p.CHS;
                 const int r = (int)__umulhi((unsigned)rem, p.div_twp);
@@ -140,13 +143,13 @@ __global__ void __launch_bounds__(256, 2) conv_mfma_kernel(ConvArgs p) {
         const int tap0 = (st - c * stages_per_chunk) * p.TT;
 #pragma unroll
         for (int e = 0; e < WR; ++e) {
-            const int idx4 = tid + e * 256;
+            const int idx4 = tid + e * NT;
             if (idx4 < KSTAGE * (BM / 4)) *reinterpret_cast<float4*>(ws + idx4 * 4) = wv[e];
         }
         if (tap0 == 0) {
 #pragma unroll
             for (int e = 0; e < XR; ++e) {
-                const int idx = tid + e * 256;
+                const int idx = tid + e * NT;
                 if (idx < p.xs_total) xs[idx] = apply_act(xv[e], p.pre_act, p.pre_slope);
             }
         }
@@ -246,7 +249,7 @@ static int launch_conv_xr(ConvArgs& p, hipStream_t stream, size_t lds) {
     const long gx = (long)p.N * p.tiles_h * p.tiles_w;
     if (gx > 2147483647L) return fail(AICG_E_SHAPE, "conv: too many output tiles");
     dim3 grid((unsigned)gx, (unsigned)idiv_up(p.Cout_g, BM), (unsigned)p.groups);
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, stream, p);
     return check_launch("conv_mfma_kernel");
 }
 
@@ -268,7 +271,8 @@ static int launch_conv(ConvArgs& p, hipStream_t stream) {
     // channels per K chunk: as many as keep the staged patch within 8 prefetch registers per thread (2048 floats)
     // and a weight stage within KSTAGE rows; never (much) more than the layer has
     p.BKC = 32;
-    while (p.BKC > 2 && (p.BKC * p.CHS > 12 * 256 || p.BKC >= 2 * p.Cin_g)) p.BKC >>= 1;
+    constexpr int XRMAX = (WM * WN == 8) ? 8 : 12;  // 8-wave tiles run at 4 waves/SIMD: 128 registers per lane
+    while (p.BKC > 2 && (p.BKC * p.CHS > XRMAX * 64 * WM * WN || p.BKC >= 2 * p.Cin_g)) p.BKC >>= 1;
     p.BKClog2 = ilog2(p.BKC);
     {   // taps per weight stage: as few, equally sized stages per chunk as fit KSTAGE rows
         const int cap = imax(1, KSTAGE / p.BKC);
@@ -282,7 +286,7 @@ static int launch_conv(ConvArgs& p, hipStream_t stream) {
     p.div_twp = div_mul(p.TWp);
     // + 2 weight rows of slack: the MFMA loop's last (discarded) fragment prefetch reads one k-step past the stage
     const size_t lds = (size_t)(p.xs_elems + (KSTAGE + 2) * BM) * sizeof(float);
-    const int xr = idiv_up(p.xs_total, 256);
+    const int xr = idiv_up(p.xs_total, 64 * WM * WN);
     if (lds > 160 * 1024 || (long)p.xs_total * p.CHS >= (1L << 32))
         return fail(AICG_E_LDS, "conv: input patch of %d x %d x %d floats is too large for one workgroup (stride/kernel too big: "
                                 "re-express the layer with the phase decomposition used for Cin = 1 convs)", p.BKC, p.TH_in, p.TWp);
@@ -352,7 +356,8 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
     auto blocks = [&](int bm, int bn) { return (long)idiv_up(M, bm) * p.groups * ldiv_up(npos, bn); };
     const long want = 512;
     if (BM == 160 && blocks(160, 128) >= want) return launch_conv<160, 128, 1, 4>(p, st);
-    if (BM == 128 && blocks(128, 128) >= want) return launch_conv<128, 128, 2, 2>(p, st);
+    static const bool eight = getenv("AICG_CONV_8WAVE") ? atoi(getenv("AICG_CONV_8WAVE")) != 0 : true;
+    if (BM == 128 && blocks(128, 128) >= want) return eight ? launch_conv<128, 128, 2, 4>(p, st) : launch_conv<128, 128, 2, 2>(p, st);
     if (BM == 96 && blocks(96, 128) >= want) return launch_conv<96, 128, 1, 4>(p, st);
     if (M > 32) {
         if (blocks(64, 128) >= want) return launch_conv<64, 128, 2, 2>(p, st);

@@ -201,10 +201,19 @@ class VC(object):
 
     def pipeline(self, model, net_g, sid, audio, input_audio_path, times, f0_up_key, f0_method, file_index, index_rate,
                  if_f0, filter_radius, tgt_sr, resample_sr, rms_mix_rate, version, protect, crepe_hop_length, f0_file=None,
-                 noise_fn=None, group=None):
+                 noise_fn=None, group=None, noise_seed=None):
         """Same contract as the reference (:474-653): float32 16 kHz mono in, int16 at tgt_sr out.
-        `noise_fn(chunk_index, T) -> (noise_z, noise_src)` injects the synthesizer noise (tests); `group` shards the
-        chunk loop over the ranks of a torch.distributed process group."""
+        `noise_fn(chunk_index, start, end) -> (noise_z, noise_src)` injects the synthesizer noise (tests); `noise_seed`
+        instead draws it from a per-chunk seeded device generator, which makes the output independent of how chunks are
+        distributed over ranks; `group` shards the chunk loop over the ranks of a torch.distributed process group."""
+        if noise_fn is None and noise_seed is not None:
+            inter, upp = net_g.inter_channels, net_g.upp
+
+            def noise_fn(ci, s, e, _seed=int(noise_seed)):
+                g = torch.Generator(device=self.device).manual_seed(_seed + ci)
+                T = 2 * ((e - s - 400) // 320 + 1)
+                return (torch.randn((1, inter, T), generator=g, device=self.device),
+                        torch.randn(T * upp, generator=g, device=self.device))
         index = big_npy = None
         if file_index != "" and os.path.exists(file_index) and index_rate != 0:
             try:

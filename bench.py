@@ -60,7 +60,7 @@ def one_step(mdx, vc, hub, net_g, wave44_dev, wave16, group):
     mdx_s = time.perf_counter() - t0
     times = [0, 0, 0]
     out = vc.pipeline(hub, net_g, 0, wave16, "synthetic.wav", times, 0, "rmvpe", "", 0.5, 1, 3, 40000, 0, 0.25, "v2", 0.33,
-                      128, group=group)
+                      128, group=group, noise_seed=1234)
     return sep, out, times, dict(vc.last_profile, mdx_s=mdx_s)
 
 
@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--track-seconds", type=float, default=TRACK_S)
+    ap.add_argument("--dump", type=str, default=None, help="write the last step's outputs (npz) for cross-checking runs")
     args = ap.parse_args()
 
     import torch.distributed as td
@@ -110,12 +111,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if os.environ.get("AICG_FORCE_DEVICE") is not None:   # debugging aid: several ranks on one GPU (with gloo)
+        local = int(os.environ["AICG_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("AICG_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            td.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            td.init_process_group(backend=backend, rank=rank, world_size=world)
 
     from aicovergen_amd import ops
     from synthetic.inputs import song_like, vocal_like
@@ -176,6 +183,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
+        if args.dump:
+            np.savez_compressed(args.dump, sep=sep.cpu().numpy()[:, ::7], out=out)
         print(json.dumps(res))
     if world > 1:
         td.destroy_process_group()

@@ -39,6 +39,9 @@ extern "C" {
 const char* aicg_last_error(void);
 /* ABI version; bumped whenever a signature changes */
 int aicg_abi_version(void);
+/* Diagnostic: pure v_mfma_f32_32x32x2_f32 issue loop (n_blocks x 256 threads, 4*iters MFMAs per wave) to calibrate the
+ * attainable fp32-MFMA rate of the device under load; out: n_blocks*256 floats. */
+int aicg_mfma_probe(float* out, int n_blocks, int iters, float seed, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Framed STFT / iSTFT  (replaces torch.stft / torch.istft as used by MDXModel.stft / .istft,
