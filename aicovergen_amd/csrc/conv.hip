@@ -238,6 +238,175 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 4)) conv_mfm
     }
 }
 
+// ---- narrow-M variant on v_mfma_f32_16x16x4_f32 ------------------------------------------------------------------------
+// Layers with 16 or 48 output channels (RMVPE level 0, the 48-channel first level of the MDX-Net U-Net) waste 50 % / 25 % of a
+// 32-row MFMA tile; the 16x16x4 instruction has the same FLOP rate (32-cycle issue) and tiles M in steps of 16.
+// Same staging pipeline as conv_mfma_kernel; A[m = l&15][k = l>>4], B[k = l>>4][n = l&15], D: col = l&15, row = 4*(l>>4) + reg.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int BM, int XR>
+__global__ void __launch_bounds__(256, 2) conv_mfma16_kernel(ConvArgs p) {
+    constexpr int NT = 256, BN = 256;
+    constexpr int TM = BM / 16;   // 16-row tiles per wave (every wave covers all BM rows)
+    constexpr int TN = 4;         // 16-column tiles per wave: 64 positions per wave, 4 waves
+    constexpr int WR = (KSTAGE * BM / 4 + NT - 1) / NT;
+    HIP_DYNAMIC_SHARED(float, smem)
+    float* xs = smem;
+    float* ws = smem + p.xs_elems;
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int q = lane >> 4, r16 = lane & 15;
+    const int bx = blockIdx.x;
+    const int tw_i = bx % p.tiles_w;
+    const int th_i = (bx / p.tiles_w) % p.tiles_h;
+    const int n = bx / (p.tiles_w * p.tiles_h);
+    const int w0 = tw_i * p.TW, h0 = th_i * p.TH;
+    const int m_base = blockIdx.y * BM;
+    const int g = blockIdx.z;
+    int boff[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nl = wn * 64 + j * 16 + r16;
+        const int jh = nl >> p.TWlog2, jw = nl & (p.TW - 1);
+        boff[j] = jh * p.sh * p.TWp + jw * p.sw + q * p.CHS;
+    }
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+    const float* xg = p.x + (long)n * p.x_sn + (long)g * p.Cin_g * p.x_sc;
+    const float* wg = p.w + (long)g * p.w_group_stride;
+    const int hin0 = h0 * p.sh - p.ph, win0 = w0 * p.sw - p.pw;
+    const int stages_per_chunk = (p.taps + p.TT - 1) / p.TT;
+    const int nstages = p.nchunk * stages_per_chunk;
+    float xv[XR];
+    float4 wv[WR];
+    auto prefetch = [&](int st) {
+        const int c = st / stages_per_chunk;
+        const int tap0 = (st - c * stages_per_chunk) * p.TT;
+        const int rows = imin(p.TT, p.taps - tap0) << p.BKClog2;
+        const float* wrow0 = wg + ((long)tap0 * p.Cin_pad + (long)c * p.BKC) * p.Mpad;
+#pragma unroll
+        for (int e = 0; e < WR; ++e) {
+            const int idx4 = tid + e * NT;
+            const int r = idx4 / (BM / 4);
+            const int c4 = idx4 - r * (BM / 4);
+            const int mcol = m_base + c4 * 4;
+            const int tt = r >> p.BKClog2, ci = r & (p.BKC - 1);
+            const bool ok = r < rows && mcol < p.Mpad;
+            const long off = ok ? ((long)tt * p.Cin_pad + ci) * p.Mpad + mcol : 0;
+            const float4 t = *reinterpret_cast<const float4*>(wrow0 + off);
+            wv[e] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (tap0 == 0) {
+#pragma unroll
+            for (int e = 0; e < XR; ++e) {
+                const int idx = tid + e * NT;
+                const int ci = (int)__umulhi((unsigned)idx, p.div_chs);
+                const int rem = idx - ci * p.CHS;
+                const int r = (int)__umulhi((unsigned)rem, p.div_twp);
+                const int col = rem - r * p.TWp;
+                const int cg = c * p.BKC + ci;
+                const int hin = hin0 + r, win = win0 + col;
+                const bool ok = idx < p.xs_total && cg < p.Cin_g && col < p.TW_in && hin >= 0 && hin < p.H && win >= 0 && win < p.W;
+                const long off = ok ? (long)cg * p.x_sc + (long)hin * p.x_sh + win : 0;
+                const float t = xg[off];
+                xv[e] = ok ? t : 0.f;
+            }
+        }
+    };
+    auto commit = [&](int st) {
+        const int c = st / stages_per_chunk;
+        const int tap0 = (st - c * stages_per_chunk) * p.TT;
+#pragma unroll
+        for (int e = 0; e < WR; ++e) {
+            const int idx4 = tid + e * NT;
+            if (idx4 < KSTAGE * (BM / 4)) *reinterpret_cast<float4*>(ws + idx4 * 4) = wv[e];
+        }
+        if (tap0 == 0) {
+#pragma unroll
+            for (int e = 0; e < XR; ++e) {
+                const int idx = tid + e * NT;
+                if (idx < p.xs_total) xs[idx] = apply_act(xv[e], p.pre_act, p.pre_slope);
+            }
+        }
+    };
+    prefetch(0);
+    for (int st = 0; st < nstages; ++st) {
+        __syncthreads();
+        commit(st);
+        __syncthreads();
+        if (st + 1 < nstages) prefetch(st + 1);
+        const int c = st / stages_per_chunk;
+        const int tap0 = (st - c * stages_per_chunk) * p.TT;
+        const int nt = imin(p.TT, p.taps - tap0);
+        int kh = tap0 / p.KW, kw = tap0 - kh * p.KW, kk = 0;
+        const int nsteps = nt * (p.BKC >> 2);  // k-steps of 4 rows
+        const float* wt = ws + q * BM + r16;
+        float a0[TM], b0[TN], a1[TM], b1[TN];
+        auto fetch = [&](float (&a)[TM], float (&b)[TN], int s) {
+            const float* xt = xs + kh * p.dh * p.TWp + kw * p.dw + kk * p.CHS;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = wt[s * 4 * BM + i * 16];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[j] = xt[boff[j]];
+            kk += 4;
+            if (kk == p.BKC) { kk = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
+        };
+        auto mma = [&](float (&a)[TM], float (&b)[TN]) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        };
+        fetch(a0, b0, 0);
+        int s = 0;
+        for (; s + 2 <= nsteps; s += 2) {
+            fetch(a1, b1, s + 1);
+            mma(a0, b0);
+            fetch(a0, b0, s + 2);
+            mma(a1, b1);
+        }
+        if (s < nsteps) mma(a0, b0);
+    }
+    const long y_base = (long)n * p.y_sn, r_base = (long)n * p.r_sn;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nl = wn * 64 + j * 16 + r16;
+        const int ho = h0 + (nl >> p.TWlog2), wo = w0 + (nl & (p.TW - 1));
+        const bool col_ok = ho < p.Ho && wo < p.Wo;
+        const long y_col = y_base + (long)ho * p.y_sh + wo, r_col = r_base + (long)ho * p.r_sh + wo;
+        float rv[TM * 4], yv[TM * 4], bv[TM * 4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m_base + i * 16 + q * 4 + r;
+                const bool ok = col_ok && m < p.Cout_g;
+                const int co = g * p.Cout_g + m;
+                bv[i * 4 + r] = (ok && p.bias) ? p.bias[co] : 0.f;
+                rv[i * 4 + r] = (ok && p.res) ? p.res[r_col + (long)co * p.r_sc] : 0.f;
+                yv[i * 4 + r] = (ok && p.accumulate) ? p.y[y_col + (long)co * p.y_sc] : 0.f;
+            }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m_base + i * 16 + q * 4 + r;
+                if (!(col_ok && m < p.Cout_g)) continue;
+                const int co = g * p.Cout_g + m;
+                float v = acc[i][j][r] + bv[i * 4 + r];
+                if (p.res_first) v += rv[i * 4 + r];
+                v = apply_act(v, p.act, p.act_slope);
+                if (!p.res_first) v += rv[i * 4 + r];
+                p.y[y_col + (long)co * p.y_sc] = v * p.out_scale + yv[i * 4 + r];
+            }
+    }
+}
+
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static unsigned div_mul(int d) { return (unsigned)((0x100000000ULL + (unsigned long long)d - 1) / (unsigned long long)d); }
 
@@ -253,15 +422,32 @@ static int launch_conv_xr(ConvArgs& p, hipStream_t stream, size_t lds) {
     return check_launch("conv_mfma_kernel");
 }
 
+// Output tile = TH x TW positions with TH*TW = BN.  A flat 1 x BN tile re-stages (KH-1) halo rows per output row; for 2-D
+// layers pick the power-of-two TW (>= 16 for coalesced patch rows) that minimises staged input elements over the layer.
+static int choose_tile_width(const ConvArgs& p, int BN) {
+    int TW = 1 << ilog2(p.Wo);
+    if (TW > BN) TW = BN;
+    if (p.Ho == 1) return BN;
+    static const bool square = getenv("AICG_CONV_SQUARE") ? atoi(getenv("AICG_CONV_SQUARE")) != 0 : true;
+    if (!square) return TW;
+    int best = TW;
+    long best_cost = -1;
+    for (int tw = TW; tw >= 16; tw >>= 1) {
+        const int th = BN / tw;
+        const int th_in = (th - 1) * p.sh + (p.KH - 1) * p.dh + 1;
+        const int tw_in = (tw - 1) * p.sw + (p.KW - 1) * p.dw + 1;
+        const long cost = (long)th_in * (tw_in | 1) * idiv_up(p.Wo, tw) * idiv_up(p.Ho, th);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = tw; }
+    }
+    return best;
+}
+
 template <int BM, int BN, int WM, int WN>
 static int launch_conv(ConvArgs& p, hipStream_t stream) {
     // output patch: TW (power of two) columns x TH rows = BN positions
-    int TW = 1 << ilog2(p.Wo);
-    if (TW > BN) TW = BN;
-    if (p.Ho == 1) TW = BN;
-    p.TW = TW;
-    p.TWlog2 = ilog2(TW);
-    p.TH = BN / TW;
+    p.TW = choose_tile_width(p, BN);
+    p.TWlog2 = ilog2(p.TW);
+    p.TH = BN / p.TW;
     p.TH_in = (p.TH - 1) * p.sh + (p.KH - 1) * p.dh + 1;
     p.TW_in = (p.TW - 1) * p.sw + (p.KW - 1) * p.dw + 1;
     p.TWp = p.TW_in | 1;
@@ -293,6 +479,49 @@ static int launch_conv(ConvArgs& p, hipStream_t stream) {
     if (xr <= 8) return launch_conv_xr<BM, BN, WM, WN, 8>(p, stream, lds);
     if (xr <= 12) return launch_conv_xr<BM, BN, WM, WN, 12>(p, stream, lds);
     return fail(AICG_E_LDS, "conv: a 2-channel input patch of %d floats exceeds the staging budget", p.xs_total);
+}
+
+template <int BM>
+static int launch_conv16(ConvArgs& p, hipStream_t stream) {
+    constexpr int BN = 256;
+    p.TW = choose_tile_width(p, BN);
+    p.TWlog2 = ilog2(p.TW);
+    p.TH = BN / p.TW;
+    p.TH_in = (p.TH - 1) * p.sh + (p.KH - 1) * p.dh + 1;
+    p.TW_in = (p.TW - 1) * p.sw + (p.KW - 1) * p.dw + 1;
+    p.TWp = p.TW_in | 1;
+    p.CHS = p.TH_in * p.TWp;
+    p.tiles_w = idiv_up(p.Wo, p.TW);
+    p.tiles_h = idiv_up(p.Ho, p.TH);
+    p.BKC = 32;
+    while (p.BKC > 4 && (p.BKC * p.CHS > 12 * 256 || p.BKC >= 2 * p.Cin_g)) p.BKC >>= 1;
+    p.BKClog2 = ilog2(p.BKC);
+    {
+        const int cap = imax(1, KSTAGE / p.BKC);
+        const int nstg = idiv_up(p.taps, cap);
+        p.TT = idiv_up(p.taps, nstg);
+    }
+    p.nchunk = idiv_up(p.Cin_g, p.BKC);
+    p.xs_total = p.BKC * p.CHS;
+    p.xs_elems = (p.xs_total + 3) & ~3;
+    p.div_chs = div_mul(p.CHS);
+    p.div_twp = div_mul(p.TWp);
+    const size_t lds = (size_t)(p.xs_elems + (KSTAGE + 4) * BM) * sizeof(float);
+    const int xr = idiv_up(p.xs_total, 256);
+    if (lds > 160 * 1024 || xr > 12 || (long)p.xs_total * p.CHS >= (1L << 32)) return 1;  // caller falls back to the 32x32 kernel
+    const long gx = (long)p.N * p.tiles_h * p.tiles_w;
+    if (gx > 2147483647L) return fail(AICG_E_SHAPE, "conv: too many output tiles");
+    dim3 grid((unsigned)gx, (unsigned)idiv_up(p.Cout_g, BM), (unsigned)p.groups);
+    if (xr <= 8) {
+        auto kern = conv_mfma16_kernel<BM, 8>;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
+    } else {
+        auto kern = conv_mfma16_kernel<BM, 12>;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
+    }
+    return check_launch("conv_mfma16_kernel");
 }
 
 }  // namespace aicg
@@ -351,6 +580,14 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
     }
     const long npos = (long)p.N * Ho * Wo;
     hipStream_t st = (hipStream_t)stream;
+    // narrow layers (16 / 48 output channels, at least 3 input channels, enough positions): 16x16x4 MFMA tiles
+    static const bool use16 = getenv("AICG_CONV_M16") ? atoi(getenv("AICG_CONV_M16")) != 0 : true;
+    if (use16 && p.Cin_g >= 3 && npos >= 256L * 256) {
+        int rc = 1;
+        if (M > 32 && M <= 48) rc = launch_conv16<48>(p, st);
+        else if (M <= 16) rc = launch_conv16<16>(p, st);
+        if (rc <= 0) return rc;   // launched (0) or failed with an error code (< 0); 1 = not applicable
+    }
     // A launch should give each of the 256 CUs at least ~2 workgroups: shrink the tile for small problems
     // (HuBERT / enc_p GEMMs over a few thousand frames), M first (keeps the wide, coalesced N tile), then N.
     auto blocks = [&](int bm, int bn) { return (long)idiv_up(M, bm) * p.groups * ldiv_up(npos, bn); };
