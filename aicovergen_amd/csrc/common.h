@@ -45,6 +45,16 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     return apply_act_slow(v, act, slope);
 }
 
+// Workgroup barrier that orders LDS traffic only: unlike __syncthreads() it does not drain the global loads a wave still
+// has in flight into registers (the producer waves of conv_ws_kernel keep one stage of loads outstanding across it).
+__device__ __forceinline__ void lds_barrier() {
+#ifdef AICG_EMULATED
+    __builtin_amdgcn_s_barrier();
+#else
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
 // block->XCD aware remap (guide T1, bijective form): consecutive logical ids share an XCD's L2.
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
     const unsigned nx = 8;

@@ -15,6 +15,8 @@
 // into LDS once -- with the fused pre-activation applied once per element, not once per tap -- and
 // every tap reads it at a shifted offset.  Lane l of a wave feeds the MFMA with
 // A[k = l>>5][m = l&31] and B[k = l>>5][n = l&31]: both are unit-stride, conflict-free ds_read_b32.
+#include <type_traits>
+
 #include "common.h"
 
 #include <cstdlib>
@@ -42,6 +44,7 @@ struct ConvArgs {
     int TW, TWlog2, TH, TH_in, TW_in, TWp, CHS, BKC, BKClog2, TT, tiles_w, tiles_h, nchunk, taps, Mpad, Cin_pad, xs_elems, xs_total;
     unsigned div_chs, div_twp;  // ceil(2^32 / d) multipliers: idx / d == umulhi(idx, mul) for idx * d < 2^32
     long w_group_stride;
+    int dbg;  // AICG_CONV_ABLATE bits (profiling only): 1 no global loads, 2 no LDS commit, 4 no barriers, 8 no MFMA loop, 16 no epilogue
 };
 
 static constexpr int KSTAGE = 64;  // max K rows of packed weights staged per barrier pair
@@ -107,6 +110,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 4)) conv_mfm
         const int rows = imin(p.TT, p.taps - tap0) << p.BKClog2;
         // packed weights: [tap][Cin_pad][Mpad]; stage row r = (tap tt = r / BKC, channel c*BKC + r % BKC)
         const float* wrow0 = wg + ((long)tap0 * p.Cin_pad + (long)c * p.BKC) * p.Mpad;
+        if (p.dbg & 1) return;
 #pragma unroll
         for (int e = 0; e < WR; ++e) {
             const int idx4 = tid + e * NT;
@@ -141,6 +145,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 4)) conv_mfm
     auto commit = [&](int st) {
         const int c = st / stages_per_chunk;
         const int tap0 = (st - c * stages_per_chunk) * p.TT;
+        if (p.dbg & 2) return;
 #pragma unroll
         for (int e = 0; e < WR; ++e) {
             const int idx4 = tid + e * NT;
@@ -157,10 +162,11 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 4)) conv_mfm
 
     prefetch(0);
     for (int st = 0; st < nstages; ++st) {
-        __syncthreads();  // every wave has finished the MFMAs of the previous stage: LDS may be overwritten
+        if (!(p.dbg & 4)) __syncthreads();  // every wave has finished the MFMAs of the previous stage: LDS may be overwritten
         commit(st);
-        __syncthreads();
+        if (!(p.dbg & 4)) __syncthreads();
         if (st + 1 < nstages) prefetch(st + 1);  // in flight during the MFMA loop below
+        if (p.dbg & 8) continue;
 
         const int c = st / stages_per_chunk;
         const int tap0 = (st - c * stages_per_chunk) * p.TT;
@@ -203,6 +209,7 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 4)) conv_mfm
     // ---- epilogue: y = [y +] out_scale * (act(acc + bias [+ res]) [+ res]) ------------------------------------
     // res / y may alias (in-place residual), so the compiler cannot move a load across a store: all operand loads
     // of a 32x32 tile are issued first, then the 16 results per lane are formed and stored.
+    if (p.dbg & 16) { if (acc[0][0][0] != 12345.f) return; }
     const long y_base = (long)n * p.y_sn, r_base = (long)n * p.r_sn;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -407,6 +414,269 @@ __global__ void __launch_bounds__(256, 2) conv_mfma16_kernel(ConvArgs p) {
     }
 }
 
+// ---- wave-specialised variant ------------------------------------------------------------------------------------------
+// Ablation of the kernel above on MI355X (MDX-Net level 1, 96 -> 96 channels 3x3, 5.97 ms): MFMA loop alone 4.25 ms, staging +
+// epilogue alone 2.27 ms -- co-resident workgroups run in lockstep, so their staging phases coincide and the matrix pipe idles.
+// Here 4 producer waves (one per SIMD) stage stage s+1 (global -> registers -> the other LDS buffer) while the WM x WN consumer
+// waves run the MFMAs of stage s; one LDS-only workgroup barrier per stage hands the buffers over.  A producer's VALU / VMEM /
+// LDS-write instructions co-issue with the consumer wave's MFMAs on the same SIMD.
+//   LDS: [patch 0][patch 1][weights 0][weights 1]; the patch buffer alternates per channel chunk, the weight buffer per stage.
+//   Producer addressing is hoisted: element e of a thread always maps to the same (channel-in-chunk, row, column) of the patch and
+//   the same (tap-in-stage, channel, m) of the weight stage, so its offsets / spatial validity are computed once per workgroup and a
+//   stage costs one add + one compare per load.  The regions are padded to whole producer passes: LDS stores are unconditional.
+template <int BM, int KS>
+struct WsGeom {
+    static constexpr int PNT = 256;
+    static constexpr int WR = (KS * BM / 4 + PNT - 1) / PNT;
+    static constexpr int WS_ELEMS = ((KS + 2) * BM > WR * PNT * 4) ? (KS + 2) * BM : WR * PNT * 4;
+};
+
+template <int BM, int BN, int WM, int WN, int XR, int KS>
+__global__ void __launch_bounds__(64 * (WM * WN + 4), (WM * WN == 4 ? 4 : 3)) conv_ws_kernel(ConvArgs p) {
+    constexpr int CW = WM * WN, CNT = 64 * CW, PNT = 256;
+    constexpr int TM = BM / (32 * WM);
+    constexpr int TN = BN / (32 * WN);
+    constexpr int WR = WsGeom<BM, KS>::WR;
+    constexpr int WS_ELEMS = WsGeom<BM, KS>::WS_ELEMS;
+    constexpr int XS_ELEMS = XR * PNT;
+    HIP_DYNAMIC_SHARED(float, smem)
+    float* const xs0 = smem;
+    float* const ws0 = smem + 2 * XS_ELEMS;
+
+    const int tid = threadIdx.x;
+    const int bx = (p.dbg & 32) ? (int)blockIdx.x : (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int tw_i = bx % p.tiles_w;
+    const int th_i = (bx / p.tiles_w) % p.tiles_h;
+    const int n = bx / (p.tiles_w * p.tiles_h);
+    const int w0 = tw_i * p.TW, h0 = th_i * p.TH;
+    const int m_base = blockIdx.y * BM;
+    const int g = blockIdx.z;
+    const int stages_per_chunk = (p.taps + p.TT - 1) / p.TT;
+    const int nstages = p.nchunk * stages_per_chunk;
+
+    if (tid >= CNT) {
+        // ================= producers =================
+        const int ptid = tid - CNT;
+        const float* xg = p.x + (long)n * p.x_sn + (long)g * p.Cin_g * p.x_sc;
+        const float* wg = p.w + (long)g * p.w_group_stride + m_base;
+        if (p.dbg & 1) {
+            for (int st = 0; st < nstages; ++st) lds_barrier();
+            return;
+        }
+        // one workgroup per CU in the 8-consumer shape: nothing else runs while its consumers wait for a late stage
+        if (CW == 8) __builtin_amdgcn_s_setprio(2);
+        int poff[XR], woff[WR];
+        unsigned pmask = 0, wmask = 0;
+        {
+            const int hin0 = h0 * p.sh - p.ph, win0 = w0 * p.sw - p.pw;
+#pragma unroll
+            for (int e = 0; e < XR; ++e) {
+                const int idx = ptid + e * PNT;
+                const int ci = (int)__umulhi((unsigned)idx, p.div_chs);
+                const int rem = idx - ci * p.CHS;
+                const int r = (int)__umulhi((unsigned)rem, p.div_twp);
+                const int col = rem - r * p.TWp;
+                const int hin = hin0 + r, win = win0 + col;
+                const bool ok = idx < p.xs_total && col < p.TW_in && hin >= 0 && hin < p.H && win >= 0 && win < p.W;
+                poff[e] = ok ? (int)(ci * p.x_sc + hin * p.x_sh + win) : 0;
+                pmask |= ok ? (1u << e) : 0u;
+            }
+#pragma unroll
+            for (int e = 0; e < WR; ++e) {
+                const int idx4 = ptid + e * PNT;
+                const int r = idx4 / (BM / 4);
+                const int c4 = idx4 - r * (BM / 4);
+                const int tt = r >> p.BKClog2, ci = r & (p.BKC - 1);
+                const bool ok = m_base + c4 * 4 < p.Mpad && r < KS;
+                woff[e] = ok ? (tt * p.Cin_pad + ci) * p.Mpad + c4 * 4 : 0;
+                wmask |= ok ? (1u << e) : 0u;
+            }
+        }
+        // Two register sets: the global loads of stage st + 1 are issued before stage st is written to LDS, so a
+        // stage's load latency spans a whole consumer stage.  lds_barrier() does not wait for loads in flight.
+        auto load = [&](int c, int tap0, float4 (&wv)[WR], float (&xv)[XR]) {
+            const int wlim = (imin(p.TT, p.taps - tap0) << p.BKClog2) * (BM / 4);  // idx4 below this: a row of this stage
+            const float* wrow0 = wg + ((long)tap0 * p.Cin_pad + (long)c * p.BKC) * p.Mpad;
+#pragma unroll
+            for (int e = 0; e < WR; ++e) {
+                const bool ok = ((wmask >> e) & 1u) && (ptid + e * PNT) < wlim;
+                const float4 t = *reinterpret_cast<const float4*>(wrow0 + (ok ? woff[e] : 0));
+                wv[e] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (tap0 == 0) {  // a new channel chunk: its input patch (halo included)
+                const float* xc = xg + (long)c * p.BKC * p.x_sc;
+                const int xlim = imin(p.BKC, p.Cin_g - c * p.BKC) * p.CHS;  // idx below this: a channel the layer has
+#pragma unroll
+                for (int e = 0; e < XR; ++e) {
+                    const bool ok = ((pmask >> e) & 1u) && (ptid + e * PNT) < xlim;
+                    const float t = xc[ok ? poff[e] : 0];
+                    xv[e] = ok ? t : 0.f;
+                }
+            }
+        };
+        auto commit = [&](int st, int c, int tap0, float4 (&wv)[WR], float (&xv)[XR]) {
+            if (tap0 == 0) {
+                float* xs = xs0 + (c & 1) * XS_ELEMS + ptid;
+                if (p.pre_act == AICG_ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < XR; ++e) xs[e * PNT] = xv[e];
+                } else if (p.pre_act == AICG_ACT_LRELU) {
+#pragma unroll
+                    for (int e = 0; e < XR; ++e) xs[e * PNT] = xv[e] > 0.f ? xv[e] : xv[e] * p.pre_slope;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < XR; ++e) xs[e * PNT] = apply_act(xv[e], p.pre_act, p.pre_slope);
+                }
+            }
+            float* ws = ws0 + (st & 1) * WS_ELEMS + ptid * 4;
+#pragma unroll
+            for (int e = 0; e < WR; ++e) *reinterpret_cast<float4*>(ws + e * PNT * 4) = wv[e];
+        };
+        auto next = [&](int& c, int& tap0) {
+            tap0 += p.TT;
+            if (tap0 >= p.taps) { tap0 = 0; ++c; }
+        };
+        float4 wvA[WR], wvB[WR];
+        float xvA[XR], xvB[XR];
+        int cA = 0, tA = 0, cB = 0, tB = 0;
+        load(cA, tA, wvA, xvA);
+        for (int st = 0; st < nstages; st += 2) {
+            cB = cA; tB = tA; next(cB, tB);
+            if (st + 1 < nstages) load(cB, tB, wvB, xvB);
+            commit(st, cA, tA, wvA, xvA);
+            lds_barrier();  // stage st published (and the consumers are done with stage st - 1)
+            if (st + 1 < nstages) {
+                cA = cB; tA = tB; next(cA, tA);
+                if (st + 2 < nstages) load(cA, tA, wvA, xvA);
+                commit(st + 1, cB, tB, wvB, xvB);
+                lds_barrier();
+            }
+        }
+        return;
+    }
+
+    // ================= consumers =================
+    const int lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wm = wave / WN, wn = wave % WN;
+    int boff[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nl = wn * (TN * 32) + j * 32 + l31;
+        const int jh = nl >> p.TWlog2, jw = nl & (p.TW - 1);
+        boff[j] = jh * p.sh * p.TWp + jw * p.sw + half * p.CHS;
+    }
+    // the accumulators start from the bias (its loads overlap the wait for the first stage)
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m0 = m_base + wm * (TM * 32) + i * 32 + 4 * half;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + (r & 3) + 8 * (r >> 2);
+            float b = 0.f;
+            if (p.bias) {
+                const float t = p.bias[g * p.Cout_g + (m < p.Cout_g ? m : 0)];
+                b = m < p.Cout_g ? t : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j][r] = b;
+        }
+    }
+    const int a_off = wm * (TM * 32) + l31 + half * BM;
+    {
+        int c = 0, tap0 = 0;
+        for (int st = 0; st < nstages; ++st) {
+            lds_barrier();  // stage st is in LDS
+            if (p.dbg & 8) continue;
+            const float* xs = xs0 + (c & 1) * XS_ELEMS;
+            const float* wt = ws0 + (st & 1) * WS_ELEMS + a_off;
+            const int nt = imin(p.TT, p.taps - tap0);
+            const int nsteps = nt * (p.BKC >> 1);
+            float a0[TM], b0[TN], a1[TM], b1[TN];
+            int kh = tap0 / p.KW, kw = tap0 - kh * p.KW, kk = 0;
+            auto fetch = [&](float (&a)[TM], float (&b)[TN], int s) {
+                const float* xt = xs + kh * p.dh * p.TWp + kw * p.dw + kk * p.CHS;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = wt[s * 2 * BM + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = xt[boff[j]];
+                kk += 2;
+                if (kk == p.BKC) { kk = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
+            };
+            auto mma = [&](float (&a)[TM], float (&b)[TN]) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            };
+            fetch(a0, b0, 0);
+            int s = 0;
+            for (; s + 2 <= nsteps; s += 2) {
+                fetch(a1, b1, s + 1);
+                mma(a0, b0);
+                fetch(a0, b0, s + 2);
+                mma(a1, b1);
+            }
+            if (s < nsteps) mma(a0, b0);
+            tap0 += p.TT;
+            if (tap0 >= p.taps) { tap0 = 0; ++c; }
+        }
+    }
+    if (p.dbg & 16) { if (acc[0][0][0] != 12345.f) return; }
+
+    // ---- epilogue: y = [y +] out_scale * (act(acc [+ res]) [+ res]); interior tiles take the predicate-free path ----
+    const long y_base = (long)n * p.y_sn, r_base = (long)n * p.r_sn;
+    const bool interior = m_base + BM <= p.Cout_g && h0 + p.TH <= p.Ho && w0 + p.TW <= p.Wo;
+    auto epilogue = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nl = wn * (TN * 32) + j * 32 + l31;
+            const int ho = h0 + (nl >> p.TWlog2), wo = w0 + (nl & (p.TW - 1));
+            const bool col_ok = FULL || (ho < p.Ho && wo < p.Wo);
+            const long y_col = y_base + (long)ho * p.y_sh + wo, r_col = r_base + (long)ho * p.r_sh + wo;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m0 = m_base + wm * (TM * 32) + i * 32 + 4 * half;
+                float rv[16], yv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { rv[r] = 0.f; yv[r] = 0.f; }
+                if (p.res) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + (r & 3) + 8 * (r >> 2);
+                        const bool ok = FULL || (col_ok && m < p.Cout_g);
+                        const float t = p.res[ok ? r_col + (long)(g * p.Cout_g + m) * p.r_sc : 0];
+                        rv[r] = ok ? t : 0.f;
+                    }
+                }
+                if (p.accumulate) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + (r & 3) + 8 * (r >> 2);
+                        const bool ok = FULL || (col_ok && m < p.Cout_g);
+                        const float t = p.y[ok ? y_col + (long)(g * p.Cout_g + m) * p.y_sc : 0];
+                        yv[r] = ok ? t : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + (r & 3) + 8 * (r >> 2);
+                    if (!FULL && !(col_ok && m < p.Cout_g)) continue;
+                    float v = acc[i][j][r];
+                    if (p.res_first) v += rv[r];
+                    v = apply_act(v, p.act, p.act_slope);
+                    if (!p.res_first) v += rv[r];
+                    p.y[y_col + (long)(g * p.Cout_g + m) * p.y_sc] = v * p.out_scale + yv[r];
+                }
+            }
+        }
+    };
+    if (interior) epilogue(std::true_type{}); else epilogue(std::false_type{});
+}
+
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static unsigned div_mul(int d) { return (unsigned)((0x100000000ULL + (unsigned long long)d - 1) / (unsigned long long)d); }
 
@@ -479,6 +749,52 @@ static int launch_conv(ConvArgs& p, hipStream_t stream) {
     if (xr <= 8) return launch_conv_xr<BM, BN, WM, WN, 8>(p, stream, lds);
     if (xr <= 12) return launch_conv_xr<BM, BN, WM, WN, 12>(p, stream, lds);
     return fail(AICG_E_LDS, "conv: a 2-channel input patch of %d floats exceeds the staging budget", p.xs_total);
+}
+
+// wave-specialised launch: returns 1 when the configuration does not fit (caller uses conv_mfma_kernel)
+template <int BM, int BN, int WM, int WN, int KS>
+static int launch_conv_ws(ConvArgs& p, hipStream_t stream) {
+    p.TW = choose_tile_width(p, BN);
+    p.TWlog2 = ilog2(p.TW);
+    p.TH = BN / p.TW;
+    p.TH_in = (p.TH - 1) * p.sh + (p.KH - 1) * p.dh + 1;
+    p.TW_in = (p.TW - 1) * p.sw + (p.KW - 1) * p.dw + 1;
+    p.TWp = p.TW_in | 1;
+    p.CHS = p.TH_in * p.TWp;
+    p.tiles_w = idiv_up(p.Wo, p.TW);
+    p.tiles_h = idiv_up(p.Ho, p.TH);
+    p.BKC = 32;
+    while (p.BKC > 2 && (p.BKC * p.CHS > 12 * 256 || p.BKC >= 2 * p.Cin_g)) p.BKC >>= 1;
+    p.BKClog2 = ilog2(p.BKC);
+    {
+        const int cap = imax(1, KS / p.BKC);
+        const int nstg = idiv_up(p.taps, cap);
+        p.TT = idiv_up(p.taps, nstg);
+    }
+    p.nchunk = idiv_up(p.Cin_g, p.BKC);
+    p.xs_total = p.BKC * p.CHS;
+    p.xs_elems = (p.xs_total + 3) & ~3;
+    p.div_chs = div_mul(p.CHS);
+    p.div_twp = div_mul(p.TWp);
+    const int xr = idiv_up(p.xs_total, 256) <= 8 ? 8 : 12;
+    const size_t lds = (size_t)(2 * xr * 256 + 2 * WsGeom<BM, KS>::WS_ELEMS) * sizeof(float);
+    // hoisted producer offsets are 32-bit: one channel chunk of the input / one stage of packed weights must span < 2^31 elements
+    const bool off_ok = (long)p.BKC * p.x_sc + (long)p.H * p.x_sh < (1L << 31) && (long)p.taps * p.Cin_pad * p.Mpad < (1L << 31);
+    if (lds > 160 * 1024 || p.xs_total > 12 * 256 || !off_ok || (long)p.xs_total * p.CHS >= (1L << 32)) return 1;
+    const long gx = (long)p.N * p.tiles_h * p.tiles_w;
+    if (gx > 2147483647L) return fail(AICG_E_SHAPE, "conv: too many output tiles");
+    dim3 grid((unsigned)gx, (unsigned)idiv_up(p.Cout_g, BM), (unsigned)p.groups);
+    dim3 block(64 * (WM * WN + 4));
+    if (xr == 8) {
+        auto kern = conv_ws_kernel<BM, BN, WM, WN, 8, KS>;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
+    } else {
+        auto kern = conv_ws_kernel<BM, BN, WM, WN, 12, KS>;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
+    }
+    return check_launch("conv_ws_kernel");
 }
 
 template <int BM>
@@ -580,6 +896,8 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
     }
     const long npos = (long)p.N * Ho * Wo;
     hipStream_t st = (hipStream_t)stream;
+    static const int ablate = getenv("AICG_CONV_ABLATE") ? atoi(getenv("AICG_CONV_ABLATE")) : 0;
+    p.dbg = ablate;
     // narrow layers (16 / 48 output channels, at least 3 input channels, enough positions): 16x16x4 MFMA tiles
     static const bool use16 = getenv("AICG_CONV_M16") ? atoi(getenv("AICG_CONV_M16")) != 0 : true;
     if (use16 && p.Cin_g >= 3 && npos >= 256L * 256) {
@@ -592,6 +910,15 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
     // (HuBERT / enc_p GEMMs over a few thousand frames), M first (keeps the wide, coalesced N tile), then N.
     auto blocks = [&](int bm, int bn) { return (long)idiv_up(M, bm) * p.groups * ldiv_up(npos, bn); };
     const long want = 512;
+    static const int ws = getenv("AICG_CONV_WS") ? atoi(getenv("AICG_CONV_WS")) : 1;
+    if (ws) {
+        int rc = 1;
+        if (BM == 160 && blocks(160, 128) >= want) rc = launch_conv_ws<160, 128, 1, 4, 32>(p, st);
+        else if (BM == 128 && blocks(128, 128) >= want) rc = (ws == 3) ? launch_conv_ws<128, 128, 2, 2, 32>(p, st) : launch_conv_ws<128, 128, 2, 4, 64>(p, st);
+        else if (BM == 96 && blocks(96, 128) >= want) rc = launch_conv_ws<96, 128, 1, 4, 64>(p, st);
+        else if (M > 32 && blocks(64, 128) >= want) rc = launch_conv_ws<64, 128, 2, 2, 64>(p, st);
+        if (rc <= 0) return rc;
+    }
     if (BM == 160 && blocks(160, 128) >= want) return launch_conv<160, 128, 1, 4>(p, st);
     static const bool eight = getenv("AICG_CONV_8WAVE") ? atoi(getenv("AICG_CONV_8WAVE")) != 0 : true;
     if (BM == 128 && blocks(128, 128) >= want) return eight ? launch_conv<128, 128, 2, 4>(p, st) : launch_conv<128, 128, 2, 2>(p, st);
