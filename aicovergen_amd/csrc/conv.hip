@@ -499,7 +499,7 @@ __global__ void __launch_bounds__(64 * (WM * WN + 4), (WM * WN == 4 ? 4 : 3)) co
             const float* wrow0 = wg + ((long)tap0 * p.Cin_pad + (long)c * p.BKC) * p.Mpad;
 #pragma unroll
             for (int e = 0; e < WR; ++e) {
-                const bool ok = ((wmask >> e) & 1u) && (ptid + e * PNT) < wlim;
+                const bool ok = ((wmask >> e) & 1u) && (ptid + e * PNT) < wlim && !(p.dbg & 512);
                 const float4 t = *reinterpret_cast<const float4*>(wrow0 + (ok ? woff[e] : 0));
                 wv[e] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -508,7 +508,7 @@ __global__ void __launch_bounds__(64 * (WM * WN + 4), (WM * WN == 4 ? 4 : 3)) co
                 const int xlim = imin(p.BKC, p.Cin_g - c * p.BKC) * p.CHS;  // idx below this: a channel the layer has
 #pragma unroll
                 for (int e = 0; e < XR; ++e) {
-                    const bool ok = ((pmask >> e) & 1u) && (ptid + e * PNT) < xlim;
+                    const bool ok = ((pmask >> e) & 1u) && (ptid + e * PNT) < xlim && !(p.dbg & 256);
                     const float t = xc[ok ? poff[e] : 0];
                     xv[e] = ok ? t : 0.f;
                 }
