@@ -25,14 +25,20 @@ struct AttnArgs {
     int T, H, window;
     long ldq, ldk, ldv, ldo;  // row (channel) strides
     float scale;
+    int nsplit;     // key range split over gridDim.z (split-K): partial (o, m, l) go to part, merged by attn_combine_kernel
+    float* part;    // [nsplit][H][D][T] un-normalised outputs, then [nsplit][H][T] running max, then [nsplit][H][T] running sum
 };
 
 static constexpr int KT = 32;       // keys per tile
 static constexpr int KV_LD = 33;    // LDS row stride of K/V tiles (conflict-free column reads)
 
+// Key tiles are software-pipelined: the K/V tile kt + 1 is loaded into registers while tile kt is consumed from LDS.
+// Few (query block, head) pairs exist for long single-head-group sequences (enc_p: 52 x 2), so the key range can be split over
+// gridDim.z; each split keeps its own running (max, sum) and attn_combine_kernel merges them (the usual log-sum-exp merge).
 template <int D>
 __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs p) {
     constexpr int DT = D / 32;
+    constexpr int NL = D * KT / 256;  // K (and V) elements each thread stages per tile
     __shared__ float Ks[D * KV_LD];
     __shared__ float Vs[D * KV_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -57,17 +63,36 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs p) {
     float m_run = -INFINITY, l_run = 0.f;
 
     const int ntiles = idiv_up(p.T, KT);
+    const int per = idiv_up(ntiles, p.nsplit);
+    const int kt_begin = blockIdx.z * per, kt_end = imin(ntiles, kt_begin + per);
     const int blk_q0 = blockIdx.x * 128;
-    for (int kt = 0; kt < ntiles; ++kt) {
+    float kpre[NL], vpre[NL];
+    auto prefetch = [&](int kt) {
         const int j0 = kt * KT;
-        __syncthreads();
-        for (int idx = tid; idx < D * KT; idx += 256) {
+#pragma unroll
+        for (int e = 0; e < NL; ++e) {
+            const int idx = tid + e * 256;
             const int d = idx >> 5, j = idx & 31;
             const bool ok = (j0 + j) < p.T;
-            Ks[d * KV_LD + j] = ok ? kh[(long)d * p.ldk + j0 + j] : 0.f;
-            Vs[d * KV_LD + j] = ok ? vh[(long)d * p.ldv + j0 + j] : 0.f;
+            const int jj = ok ? j0 + j : 0;
+            const float tk = kh[(long)d * p.ldk + jj], tv = vh[(long)d * p.ldv + jj];
+            kpre[e] = ok ? tk : 0.f;
+            vpre[e] = ok ? tv : 0.f;
+        }
+    };
+    if (kt_begin < kt_end) prefetch(kt_begin);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int j0 = kt * KT;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < NL; ++e) {
+            const int idx = tid + e * 256;
+            const int d = idx >> 5, j = idx & 31;
+            Ks[d * KV_LD + j] = kpre[e];
+            Vs[d * KV_LD + j] = vpre[e];
         }
         __syncthreads();
+        if (kt + 1 < kt_end) prefetch(kt + 1);
         // S^T tile: rows = keys, cols = queries
         f32x16 st;
 #pragma unroll
@@ -90,12 +115,15 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs p) {
         }
         // online softmax over this tile's 32 keys of query qi
         float m_t = -INFINITY;
+        if (j0 + KT > p.T) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (j >= p.T) st[r] = -INFINITY;
-            m_t = fmaxf(m_t, st[r]);
+            for (int r = 0; r < 16; ++r) {
+                const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (j >= p.T) st[r] = -INFINITY;
+            }
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m_t = fmaxf(m_t, st[r]);
         m_t = fmaxf(m_t, __shfl_xor(m_t, 32));
         const float m_new = fmaxf(m_run, m_t);
         const float alpha = expf(m_run - m_new);
@@ -123,18 +151,68 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs p) {
             }
         }
     }
-    if (qi < p.T) {
-        const float inv = 1.f / l_run;
-        float* oh = p.o + (long)h * D * p.ldo;
+    if (qi >= p.T) return;
+    if (p.nsplit > 1) {
+        const long sh = (long)blockIdx.z * p.H + h;
+        float* po = p.part + sh * D * p.T;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                oh[(long)d * p.ldo + qi] = acc[dt][r] * inv;
+                po[(long)d * p.T + qi] = acc[dt][r];
             }
-        if (p.lse && half == 0) p.lse[(long)h * p.T + qi] = m_run + logf(l_run);
+        if (half == 0) {
+            float* pm = p.part + (long)p.nsplit * p.H * D * p.T;
+            pm[sh * p.T + qi] = m_run;
+            pm[((long)p.nsplit * p.H + sh) * p.T + qi] = l_run;
+        }
+        return;
     }
+    const float inv = 1.f / l_run;
+    float* oh = p.o + (long)h * D * p.ldo;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            oh[(long)d * p.ldo + qi] = acc[dt][r] * inv;
+        }
+    if (p.lse && half == 0) p.lse[(long)h * p.T + qi] = m_run + logf(l_run);
+}
+
+// merge of the split-K partials: o = sum_s acc_s e^{m_s - m} / sum_s l_s e^{m_s - m}; grid (T/256, H, D/16)
+__global__ void __launch_bounds__(256) attn_combine_kernel(AttnArgs p, int D) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int h = blockIdx.y;
+    if (i >= p.T) return;
+    const float* pm = p.part + (long)p.nsplit * p.H * D * p.T;
+    const float* pl = pm + (long)p.nsplit * p.H * p.T;
+    float m = -INFINITY;
+    for (int s = 0; s < p.nsplit; ++s) m = fmaxf(m, pm[((long)s * p.H + h) * p.T + i]);
+    float w[16];
+    float l = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        w[s] = 0.f;
+        if (s < p.nsplit) {
+            const long sh = (long)s * p.H + h;
+            w[s] = expf(pm[sh * p.T + i] - m);
+            l += pl[sh * p.T + i] * w[s];
+        }
+    }
+    const float inv = 1.f / l;
+    float* oh = p.o + (long)h * D * p.ldo;
+    const int d0 = blockIdx.z * 16;
+#pragma unroll 4
+    for (int d = d0; d < d0 + 16; ++d) {
+        float a = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            if (s < p.nsplit) a += p.part[(((long)s * p.H + h) * D + d) * p.T + i] * w[s];
+        oh[(long)d * p.ldo + i] = a * inv;
+    }
+    if (p.lse && blockIdx.z == 0) p.lse[(long)h * p.T + i] = m + logf(l);
 }
 
 // Relative-position VALUE term: o_i += sum_{|j-i|<=w} P_ij E^v_{j-i+w}, with P rebuilt from the saved
@@ -182,26 +260,45 @@ __global__ void __launch_bounds__(64) attn_relv_kernel(AttnArgs p, const float* 
 
 using namespace aicg;
 
+static int attention_launch(AttnArgs& p, int D, hipStream_t stream) {
+    dim3 grid((unsigned)idiv_up(p.T, 128), (unsigned)p.H, (unsigned)p.nsplit);
+    if (D == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_fwd_kernel<64>), grid, dim3(256), 0, stream, p);
+    else if (D == 96) hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_fwd_kernel<96>), grid, dim3(256), 0, stream, p);
+    else if (D == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_fwd_kernel<32>), grid, dim3(256), 0, stream, p);
+    else if (D == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_fwd_kernel<128>), grid, dim3(256), 0, stream, p);
+    else return fail(AICG_E_SHAPE, "aicg_attention: head dim %d not in {32,64,96,128}", D);
+    int rc = check_launch("attn_fwd_kernel");
+    if (rc != AICG_OK || p.nsplit == 1) return rc;
+    hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)idiv_up(p.T, 256), (unsigned)p.H, (unsigned)(D / 16)), dim3(256), 0, stream, p, D);
+    return check_launch("attn_combine_kernel");
+}
+
 extern "C" int aicg_attention(const float* q, const float* k, const float* v, const float* relk, float* o, float* lse, int T,
                               int H, int D, int window, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale,
                               void* stream) {
     if (!q || !k || !v || !o) return fail(AICG_E_ARG, "aicg_attention: null pointer");
     if (T < 1 || H < 1) return fail(AICG_E_SHAPE, "aicg_attention: bad shape");
-    AttnArgs p{q, k, v, relk, o, lse, T, H, window, (long)ldq, (long)ldk, (long)ldv, (long)ldo, scale};
-    dim3 grid((unsigned)idiv_up(T, 128), (unsigned)H);
-    if (D == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_fwd_kernel<64>), grid, dim3(256), 0, (hipStream_t)stream, p);
-    else if (D == 96) hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_fwd_kernel<96>), grid, dim3(256), 0, (hipStream_t)stream, p);
-    else if (D == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_fwd_kernel<32>), grid, dim3(256), 0, (hipStream_t)stream, p);
-    else if (D == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_fwd_kernel<128>), grid, dim3(256), 0, (hipStream_t)stream, p);
-    else return fail(AICG_E_SHAPE, "aicg_attention: head dim %d not in {32,64,96,128}", D);
-    return check_launch("attn_fwd_kernel");
+    AttnArgs p{q, k, v, relk, o, lse, T, H, window, (long)ldq, (long)ldk, (long)ldv, (long)ldo, scale, 1, nullptr};
+    return attention_launch(p, D, (hipStream_t)stream);
+}
+
+extern "C" int aicg_attention_split(const float* q, const float* k, const float* v, const float* relk, float* o, float* lse,
+                                    int T, int H, int D, int window, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                                    float scale, int n_splits, float* scratch, void* stream) {
+    if (!q || !k || !v || !o) return fail(AICG_E_ARG, "aicg_attention_split: null pointer");
+    if (T < 1 || H < 1) return fail(AICG_E_SHAPE, "aicg_attention_split: bad shape");
+    if (n_splits < 1 || n_splits > 16 || n_splits > idiv_up(T, KT))
+        return fail(AICG_E_ARG, "aicg_attention_split: n_splits %d not in [1, min(16, key tiles)]", n_splits);
+    if (n_splits > 1 && !scratch) return fail(AICG_E_ARG, "aicg_attention_split: scratch is required for n_splits > 1");
+    AttnArgs p{q, k, v, relk, o, lse, T, H, window, (long)ldq, (long)ldk, (long)ldv, (long)ldo, scale, n_splits, scratch};
+    return attention_launch(p, D, (hipStream_t)stream);
 }
 
 extern "C" int aicg_attention_relv(const float* q, const float* k, const float* relk, const float* relv_emb,
                                    const float* lse, float* o, int T, int H, int D, int window, int64_t ldq, int64_t ldk,
                                    int64_t ldo, float scale, void* stream) {
     if (!q || !k || !relk || !relv_emb || !lse || !o) return fail(AICG_E_ARG, "aicg_attention_relv: null pointer");
-    AttnArgs p{q, k, nullptr, relk, o, const_cast<float*>(lse), T, H, window, (long)ldq, (long)ldk, 0, (long)ldo, scale};
+    AttnArgs p{q, k, nullptr, relk, o, const_cast<float*>(lse), T, H, window, (long)ldq, (long)ldk, 0, (long)ldo, scale, 1, nullptr};
     dim3 grid((unsigned)idiv_up(T, 64), (unsigned)H);
     if (D == 96 && window == 10)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_relv_kernel<96, 21>), grid, dim3(64), 0, (hipStream_t)stream, p, relv_emb);

@@ -380,7 +380,7 @@ def rownorm_act(x, gamma, beta, act=ACT_NONE, eps=1e-5, out=None):
     return out
 
 
-def attention(q, k, v, n_heads, relk=None, relv_emb=None, window=0, scale=1.0):
+def attention(q, k, v, n_heads, relk=None, relv_emb=None, window=0, scale=1.0, n_splits=None):
     """q, k, v: (C, T) channel-major (rows may be slices of a fused QKV buffer; stride(1) == 1).
     relk: (H, 2w+1, T) precomputed q.E^k (or None); relv_emb: (2w+1, D) for the relative value term."""
     c, t = q.shape
@@ -392,8 +392,16 @@ def attention(q, k, v, n_heads, relk=None, relv_emb=None, window=0, scale=1.0):
         assert relk.is_contiguous() and relk.shape == (n_heads, 2 * window + 1, t)
     _check(q, k, v, relk, relv_emb)
     st = _stream(q)
-    _lib.call("aicg_attention", _ptr(q), _ptr(k), _ptr(v), _ptr(relk), _ptr(o), _ptr(lse), t, n_heads, d, window,
-              q.stride(0), k.stride(0), v.stride(0), o.stride(0), float(scale), st)
+    # (query block, head) pairs alone do not fill 256 CUs for a few heads: split the keys until ~1024 workgroups exist
+    blocks = -(-t // 128) * n_heads
+    splits = max(1, min(4, -(-t // 32), -(-1024 // blocks))) if n_splits is None else n_splits  # > 4: the merge pass costs more than it fills
+    if splits > 1:
+        scratch = torch.empty(splits * n_heads * (d + 2) * t, dtype=torch.float32, device=q.device)
+        _lib.call("aicg_attention_split", _ptr(q), _ptr(k), _ptr(v), _ptr(relk), _ptr(o), _ptr(lse), t, n_heads, d, window,
+                  q.stride(0), k.stride(0), v.stride(0), o.stride(0), float(scale), splits, _ptr(scratch), st)
+    else:
+        _lib.call("aicg_attention", _ptr(q), _ptr(k), _ptr(v), _ptr(relk), _ptr(o), _ptr(lse), t, n_heads, d, window,
+                  q.stride(0), k.stride(0), v.stride(0), o.stride(0), float(scale), st)
     if relv_emb is not None:
         relv_emb = relv_emb.contiguous()
         _lib.call("aicg_attention_relv", _ptr(q), _ptr(k), _ptr(relk), _ptr(relv_emb), _ptr(lse), _ptr(o), t, n_heads, d,

@@ -158,6 +158,12 @@ int aicg_rownorm_act(const float* x, const float* gamma, const float* beta, floa
 int aicg_attention(const float* q, const float* k, const float* v, const float* relk, float* o, float* lse, int T,
                    int H, int D, int window, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float scale,
                    void* stream);
+/* Same result with the key range split over n_splits workgroup groups (1..16, at most ceil(T/32)) and a log-sum-exp
+ * merge pass: fills the GPU when ceil(T/128)*H is small (enc_p: 2 heads).  scratch: n_splits * H * (D + 2) * T floats
+ * (unused when n_splits == 1). */
+int aicg_attention_split(const float* q, const float* k, const float* v, const float* relk, float* o, float* lse,
+                         int T, int H, int D, int window, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                         float scale, int n_splits, float* scratch, void* stream);
 /* o_i += sum_{|j-i|<=window} P_ij E^v_{j-i+window} (attentions.py:264-271); relv_emb: (2*window+1, D). */
 int aicg_attention_relv(const float* q, const float* k, const float* relk, const float* relv_emb,
                         const float* lse, float* o, int T, int H, int D, int window, int64_t ldq, int64_t ldk,

@@ -145,3 +145,20 @@ def test_attention_online_softmax_rescale(dev):
     ref = (F.softmax(qh @ kh.t(), -1) @ vh).t()
     o = ops.attention(dev.t(q), dev.t(k), dev.t(v), H)
     assert rel_rms(o, ref) < 1e-5
+
+
+@pytest.mark.parametrize("win", [0, 10])
+def test_attention_key_split_matches_single_pass(dev, win):
+    """Split-K over the key range + log-sum-exp merge == the single-pass kernel (also for the lse the relative-value
+    term consumes), including a split whose tiles end in the ragged last tile."""
+    torch.manual_seed(21)
+    H, D, T = 2, 96, (1205 if dev.big else 205)
+    q, k, v = torch.randn(H * D, T) * 0.4, torch.randn(H * D, T) * 0.4, torch.randn(H * D, T)
+    relk = ev = None
+    if win:
+        relk = dev.t(torch.randn(H, 2 * win + 1, T) * 0.3)
+        ev = dev.t(torch.randn(2 * win + 1, D) * 0.1)
+    one = ops.attention(dev.t(q), dev.t(k), dev.t(v), H, relk=relk, relv_emb=ev, window=win, n_splits=1)
+    for s in (2, 7):
+        many = ops.attention(dev.t(q), dev.t(k), dev.t(v), H, relk=relk, relv_emb=ev, window=win, n_splits=s)
+        assert rel_rms(many, one.cpu()) < 2e-6
