@@ -428,8 +428,113 @@ template <int BM, int KS>
 struct WsGeom {
     static constexpr int PNT = 256;
     static constexpr int WR = (KS * BM / 4 + PNT - 1) / PNT;
-    static constexpr int WS_ELEMS = ((KS + 2) * BM > WR * PNT * 4) ? (KS + 2) * BM : WR * PNT * 4;
+    static constexpr int WS_ELEMS = ((KS + 4) * BM > WR * PNT * 4) ? (KS + 4) * BM : WR * PNT * 4;  // + slack rows: discarded last fragment prefetch
 };
+
+// The producer role of the wave-specialised kernels: 256 threads (ptid) stage every K stage of one output tile.
+template <int BM, int XR, int KS, bool BOOST>
+__device__ __forceinline__ void ws_produce(const ConvArgs& p, float* xs0, float* ws0, int ptid, int n, int g, int h0, int w0,
+                                           int m_base, int nstages) {
+    constexpr int PNT = 256;
+    constexpr int WR = WsGeom<BM, KS>::WR;
+    constexpr int WS_ELEMS = WsGeom<BM, KS>::WS_ELEMS;
+    constexpr int XS_ELEMS = XR * PNT;
+    const float* xg = p.x + (long)n * p.x_sn + (long)g * p.Cin_g * p.x_sc;
+    const float* wg = p.w + (long)g * p.w_group_stride + m_base;
+    if (p.dbg & 1) {
+        for (int st = 0; st < nstages; ++st) lds_barrier();
+        return;
+    }
+    // BOOST: one workgroup per CU (8-consumer shape): nothing else runs while its consumers wait for a late stage
+    if (BOOST) __builtin_amdgcn_s_setprio(2);
+    int poff[XR], woff[WR];
+    unsigned pmask = 0, wmask = 0;
+    {
+        const int hin0 = h0 * p.sh - p.ph, win0 = w0 * p.sw - p.pw;
+#pragma unroll
+        for (int e = 0; e < XR; ++e) {
+            const int idx = ptid + e * PNT;
+            const int ci = (int)__umulhi((unsigned)idx, p.div_chs);
+            const int rem = idx - ci * p.CHS;
+            const int r = (int)__umulhi((unsigned)rem, p.div_twp);
+            const int col = rem - r * p.TWp;
+            const int hin = hin0 + r, win = win0 + col;
+            const bool ok = idx < p.xs_total && col < p.TW_in && hin >= 0 && hin < p.H && win >= 0 && win < p.W;
+            poff[e] = ok ? (int)(ci * p.x_sc + hin * p.x_sh + win) : 0;
+            pmask |= ok ? (1u << e) : 0u;
+        }
+#pragma unroll
+        for (int e = 0; e < WR; ++e) {
+            const int idx4 = ptid + e * PNT;
+            const int r = idx4 / (BM / 4);
+            const int c4 = idx4 - r * (BM / 4);
+            const int tt = r >> p.BKClog2, ci = r & (p.BKC - 1);
+            const bool ok = m_base + c4 * 4 < p.Mpad && r < KS;
+            woff[e] = ok ? (tt * p.Cin_pad + ci) * p.Mpad + c4 * 4 : 0;
+            wmask |= ok ? (1u << e) : 0u;
+        }
+    }
+    // Two register sets: the global loads of stage st + 1 are issued before stage st is written to LDS, so a
+    // stage's load latency spans a whole consumer stage.  lds_barrier() does not wait for loads in flight.
+    auto load = [&](int c, int tap0, float4 (&wv)[WR], float (&xv)[XR]) {
+        const int wlim = (imin(p.TT, p.taps - tap0) << p.BKClog2) * (BM / 4);  // idx4 below this: a row of this stage
+        const float* wrow0 = wg + ((long)tap0 * p.Cin_pad + (long)c * p.BKC) * p.Mpad;
+#pragma unroll
+        for (int e = 0; e < WR; ++e) {
+            const bool ok = ((wmask >> e) & 1u) && (ptid + e * PNT) < wlim && !(p.dbg & 512);
+            const float4 t = *reinterpret_cast<const float4*>(wrow0 + (ok ? woff[e] : 0));
+            wv[e] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (tap0 == 0) {  // a new channel chunk: its input patch (halo included)
+            const float* xc = xg + (long)c * p.BKC * p.x_sc;
+            const int xlim = imin(p.BKC, p.Cin_g - c * p.BKC) * p.CHS;  // idx below this: a channel the layer has
+#pragma unroll
+            for (int e = 0; e < XR; ++e) {
+                const bool ok = ((pmask >> e) & 1u) && (ptid + e * PNT) < xlim && !(p.dbg & 256);
+                const float t = xc[ok ? poff[e] : 0];
+                xv[e] = ok ? t : 0.f;
+            }
+        }
+    };
+    auto commit = [&](int st, int c, int tap0, float4 (&wv)[WR], float (&xv)[XR]) {
+        if (tap0 == 0) {
+            float* xs = xs0 + (c & 1) * XS_ELEMS + ptid;
+            if (p.pre_act == AICG_ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < XR; ++e) xs[e * PNT] = xv[e];
+            } else if (p.pre_act == AICG_ACT_LRELU) {
+#pragma unroll
+                for (int e = 0; e < XR; ++e) xs[e * PNT] = xv[e] > 0.f ? xv[e] : xv[e] * p.pre_slope;
+            } else {
+#pragma unroll
+                for (int e = 0; e < XR; ++e) xs[e * PNT] = apply_act(xv[e], p.pre_act, p.pre_slope);
+            }
+        }
+        float* ws = ws0 + (st & 1) * WS_ELEMS + ptid * 4;
+#pragma unroll
+        for (int e = 0; e < WR; ++e) *reinterpret_cast<float4*>(ws + e * PNT * 4) = wv[e];
+    };
+    auto next = [&](int& c, int& tap0) {
+        tap0 += p.TT;
+        if (tap0 >= p.taps) { tap0 = 0; ++c; }
+    };
+    float4 wvA[WR], wvB[WR];
+    float xvA[XR], xvB[XR];
+    int cA = 0, tA = 0, cB = 0, tB = 0;
+    load(cA, tA, wvA, xvA);
+    for (int st = 0; st < nstages; st += 2) {
+        cB = cA; tB = tA; next(cB, tB);
+        if (st + 1 < nstages) load(cB, tB, wvB, xvB);
+        commit(st, cA, tA, wvA, xvA);
+        lds_barrier();  // stage st published (and the consumers are done with stage st - 1)
+        if (st + 1 < nstages) {
+            cA = cB; tA = tB; next(cA, tA);
+            if (st + 2 < nstages) load(cA, tA, wvA, xvA);
+            commit(st + 1, cB, tB, wvB, xvB);
+            lds_barrier();
+        }
+    }
+}
 
 template <int BM, int BN, int WM, int WN, int XR, int KS>
 __global__ void __launch_bounds__(64 * (WM * WN + 4), (WM * WN == 4 ? 4 : 3)) conv_ws_kernel(ConvArgs p) {
@@ -455,103 +560,7 @@ __global__ void __launch_bounds__(64 * (WM * WN + 4), (WM * WN == 4 ? 4 : 3)) co
     const int nstages = p.nchunk * stages_per_chunk;
 
     if (tid >= CNT) {
-        // ================= producers =================
-        const int ptid = tid - CNT;
-        const float* xg = p.x + (long)n * p.x_sn + (long)g * p.Cin_g * p.x_sc;
-        const float* wg = p.w + (long)g * p.w_group_stride + m_base;
-        if (p.dbg & 1) {
-            for (int st = 0; st < nstages; ++st) lds_barrier();
-            return;
-        }
-        // one workgroup per CU in the 8-consumer shape: nothing else runs while its consumers wait for a late stage
-        if (CW == 8) __builtin_amdgcn_s_setprio(2);
-        int poff[XR], woff[WR];
-        unsigned pmask = 0, wmask = 0;
-        {
-            const int hin0 = h0 * p.sh - p.ph, win0 = w0 * p.sw - p.pw;
-#pragma unroll
-            for (int e = 0; e < XR; ++e) {
-                const int idx = ptid + e * PNT;
-                const int ci = (int)__umulhi((unsigned)idx, p.div_chs);
-                const int rem = idx - ci * p.CHS;
-                const int r = (int)__umulhi((unsigned)rem, p.div_twp);
-                const int col = rem - r * p.TWp;
-                const int hin = hin0 + r, win = win0 + col;
-                const bool ok = idx < p.xs_total && col < p.TW_in && hin >= 0 && hin < p.H && win >= 0 && win < p.W;
-                poff[e] = ok ? (int)(ci * p.x_sc + hin * p.x_sh + win) : 0;
-                pmask |= ok ? (1u << e) : 0u;
-            }
-#pragma unroll
-            for (int e = 0; e < WR; ++e) {
-                const int idx4 = ptid + e * PNT;
-                const int r = idx4 / (BM / 4);
-                const int c4 = idx4 - r * (BM / 4);
-                const int tt = r >> p.BKClog2, ci = r & (p.BKC - 1);
-                const bool ok = m_base + c4 * 4 < p.Mpad && r < KS;
-                woff[e] = ok ? (tt * p.Cin_pad + ci) * p.Mpad + c4 * 4 : 0;
-                wmask |= ok ? (1u << e) : 0u;
-            }
-        }
-        // Two register sets: the global loads of stage st + 1 are issued before stage st is written to LDS, so a
-        // stage's load latency spans a whole consumer stage.  lds_barrier() does not wait for loads in flight.
-        auto load = [&](int c, int tap0, float4 (&wv)[WR], float (&xv)[XR]) {
-            const int wlim = (imin(p.TT, p.taps - tap0) << p.BKClog2) * (BM / 4);  // idx4 below this: a row of this stage
-            const float* wrow0 = wg + ((long)tap0 * p.Cin_pad + (long)c * p.BKC) * p.Mpad;
-#pragma unroll
-            for (int e = 0; e < WR; ++e) {
-                const bool ok = ((wmask >> e) & 1u) && (ptid + e * PNT) < wlim && !(p.dbg & 512);
-                const float4 t = *reinterpret_cast<const float4*>(wrow0 + (ok ? woff[e] : 0));
-                wv[e] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            if (tap0 == 0) {  // a new channel chunk: its input patch (halo included)
-                const float* xc = xg + (long)c * p.BKC * p.x_sc;
-                const int xlim = imin(p.BKC, p.Cin_g - c * p.BKC) * p.CHS;  // idx below this: a channel the layer has
-#pragma unroll
-                for (int e = 0; e < XR; ++e) {
-                    const bool ok = ((pmask >> e) & 1u) && (ptid + e * PNT) < xlim && !(p.dbg & 256);
-                    const float t = xc[ok ? poff[e] : 0];
-                    xv[e] = ok ? t : 0.f;
-                }
-            }
-        };
-        auto commit = [&](int st, int c, int tap0, float4 (&wv)[WR], float (&xv)[XR]) {
-            if (tap0 == 0) {
-                float* xs = xs0 + (c & 1) * XS_ELEMS + ptid;
-                if (p.pre_act == AICG_ACT_NONE) {
-#pragma unroll
-                    for (int e = 0; e < XR; ++e) xs[e * PNT] = xv[e];
-                } else if (p.pre_act == AICG_ACT_LRELU) {
-#pragma unroll
-                    for (int e = 0; e < XR; ++e) xs[e * PNT] = xv[e] > 0.f ? xv[e] : xv[e] * p.pre_slope;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < XR; ++e) xs[e * PNT] = apply_act(xv[e], p.pre_act, p.pre_slope);
-                }
-            }
-            float* ws = ws0 + (st & 1) * WS_ELEMS + ptid * 4;
-#pragma unroll
-            for (int e = 0; e < WR; ++e) *reinterpret_cast<float4*>(ws + e * PNT * 4) = wv[e];
-        };
-        auto next = [&](int& c, int& tap0) {
-            tap0 += p.TT;
-            if (tap0 >= p.taps) { tap0 = 0; ++c; }
-        };
-        float4 wvA[WR], wvB[WR];
-        float xvA[XR], xvB[XR];
-        int cA = 0, tA = 0, cB = 0, tB = 0;
-        load(cA, tA, wvA, xvA);
-        for (int st = 0; st < nstages; st += 2) {
-            cB = cA; tB = tA; next(cB, tB);
-            if (st + 1 < nstages) load(cB, tB, wvB, xvB);
-            commit(st, cA, tA, wvA, xvA);
-            lds_barrier();  // stage st published (and the consumers are done with stage st - 1)
-            if (st + 1 < nstages) {
-                cA = cB; tA = tB; next(cA, tA);
-                if (st + 2 < nstages) load(cA, tA, wvA, xvA);
-                commit(st + 1, cB, tB, wvB, xvB);
-                lds_barrier();
-            }
-        }
+        ws_produce<BM, XR, KS, CW == 8>(p, xs0, ws0, tid - CNT, n, g, h0, w0, m_base, nstages);
         return;
     }
 
@@ -671,6 +680,139 @@ __global__ void __launch_bounds__(64 * (WM * WN + 4), (WM * WN == 4 ? 4 : 3)) co
                     if (!p.res_first) v += rv[r];
                     p.y[y_col + (long)(g * p.Cout_g + m) * p.y_sc] = v * p.out_scale + yv[r];
                 }
+            }
+        }
+    };
+    if (interior) epilogue(std::true_type{}); else epilogue(std::false_type{});
+}
+
+// Wave-specialised narrow-M kernel: the consumers of conv_mfma16_kernel (16x16x4 MFMA, every wave covers all BM rows x 64
+// positions of a 256-position tile) fed by ws_produce.  WsGeom pads the weight stage with 4 slack rows (one 16x16x4 k-step).
+template <int BM, int XR, int KS>
+__global__ void __launch_bounds__(512, 4) conv_ws16_kernel(ConvArgs p) {
+    constexpr int CNT = 256;
+    constexpr int TM = BM / 16, TN = 4;
+    constexpr int WS_ELEMS = WsGeom<BM, KS>::WS_ELEMS;
+    constexpr int XS_ELEMS = XR * 256;
+    HIP_DYNAMIC_SHARED(float, smem)
+    float* const xs0 = smem;
+    float* const ws0 = smem + 2 * XS_ELEMS;
+    const int tid = threadIdx.x;
+    const int bx = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int tw_i = bx % p.tiles_w;
+    const int th_i = (bx / p.tiles_w) % p.tiles_h;
+    const int n = bx / (p.tiles_w * p.tiles_h);
+    const int w0 = tw_i * p.TW, h0 = th_i * p.TH;
+    const int m_base = blockIdx.y * BM;
+    const int g = blockIdx.z;
+    const int stages_per_chunk = (p.taps + p.TT - 1) / p.TT;
+    const int nstages = p.nchunk * stages_per_chunk;
+    if (tid >= CNT) {
+        ws_produce<BM, XR, KS, false>(p, xs0, ws0, tid - CNT, n, g, h0, w0, m_base, nstages);
+        return;
+    }
+    const int lane = tid & 63, wn = tid >> 6;
+    const int q = lane >> 4, r16 = lane & 15;
+    int boff[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nl = wn * 64 + j * 16 + r16;
+        const int jh = nl >> p.TWlog2, jw = nl & (p.TW - 1);
+        boff[j] = jh * p.sh * p.TWp + jw * p.sw + q * p.CHS;
+    }
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m_base + i * 16 + q * 4 + r;
+            float b = 0.f;
+            if (p.bias) {
+                const float t = p.bias[g * p.Cout_g + (m < p.Cout_g ? m : 0)];
+                b = m < p.Cout_g ? t : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j][r] = b;
+        }
+    {
+        int c = 0, tap0 = 0;
+        for (int st = 0; st < nstages; ++st) {
+            lds_barrier();  // stage st is in LDS
+            const float* xs = xs0 + (c & 1) * XS_ELEMS;
+            const float* wt = ws0 + (st & 1) * WS_ELEMS + q * BM + r16;
+            const int nt = imin(p.TT, p.taps - tap0);
+            const int nsteps = nt * (p.BKC >> 2);  // k-steps of 4 rows
+            float a0[TM], b0[TN], a1[TM], b1[TN];
+            int kh = tap0 / p.KW, kw = tap0 - kh * p.KW, kk = 0;
+            auto fetch = [&](float (&a)[TM], float (&b)[TN], int s) {
+                const float* xt = xs + kh * p.dh * p.TWp + kw * p.dw + kk * p.CHS;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = wt[s * 4 * BM + i * 16];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = xt[boff[j]];
+                kk += 4;
+                if (kk == p.BKC) { kk = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
+            };
+            auto mma = [&](float (&a)[TM], float (&b)[TN]) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            };
+            fetch(a0, b0, 0);
+            int s = 0;
+            for (; s + 2 <= nsteps; s += 2) {
+                fetch(a1, b1, s + 1);
+                mma(a0, b0);
+                fetch(a0, b0, s + 2);
+                mma(a1, b1);
+            }
+            if (s < nsteps) mma(a0, b0);
+            tap0 += p.TT;
+            if (tap0 >= p.taps) { tap0 = 0; ++c; }
+        }
+    }
+    const long y_base = (long)n * p.y_sn, r_base = (long)n * p.r_sn;
+    const bool interior = m_base + BM <= p.Cout_g && h0 + p.TH <= p.Ho && w0 + p.TW <= p.Wo;
+    auto epilogue = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nl = wn * 64 + j * 16 + r16;
+            const int ho = h0 + (nl >> p.TWlog2), wo = w0 + (nl & (p.TW - 1));
+            const bool col_ok = FULL || (ho < p.Ho && wo < p.Wo);
+            const long y_col = y_base + (long)ho * p.y_sh + wo, r_col = r_base + (long)ho * p.r_sh + wo;
+            float rv[TM * 4], yv[TM * 4];
+#pragma unroll
+            for (int e = 0; e < TM * 4; ++e) { rv[e] = 0.f; yv[e] = 0.f; }
+            if (p.res) {
+#pragma unroll
+                for (int e = 0; e < TM * 4; ++e) {
+                    const int m = m_base + (e >> 2) * 16 + q * 4 + (e & 3);
+                    const bool ok = FULL || (col_ok && m < p.Cout_g);
+                    const float t = p.res[ok ? r_col + (long)(g * p.Cout_g + m) * p.r_sc : 0];
+                    rv[e] = ok ? t : 0.f;
+                }
+            }
+            if (p.accumulate) {
+#pragma unroll
+                for (int e = 0; e < TM * 4; ++e) {
+                    const int m = m_base + (e >> 2) * 16 + q * 4 + (e & 3);
+                    const bool ok = FULL || (col_ok && m < p.Cout_g);
+                    const float t = p.y[ok ? y_col + (long)(g * p.Cout_g + m) * p.y_sc : 0];
+                    yv[e] = ok ? t : 0.f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < TM * 4; ++e) {
+                const int m = m_base + (e >> 2) * 16 + q * 4 + (e & 3);
+                if (!FULL && !(col_ok && m < p.Cout_g)) continue;
+                float v = acc[e >> 2][j][e & 3];
+                if (p.res_first) v += rv[e];
+                v = apply_act(v, p.act, p.act_slope);
+                if (!p.res_first) v += rv[e];
+                p.y[y_col + (long)(g * p.Cout_g + m) * p.y_sc] = v * p.out_scale + yv[e];
             }
         }
     };
@@ -828,6 +970,22 @@ static int launch_conv16(ConvArgs& p, hipStream_t stream) {
     const long gx = (long)p.N * p.tiles_h * p.tiles_w;
     if (gx > 2147483647L) return fail(AICG_E_SHAPE, "conv: too many output tiles");
     dim3 grid((unsigned)gx, (unsigned)idiv_up(p.Cout_g, BM), (unsigned)p.groups);
+    static const int ws = getenv("AICG_CONV_WS") ? atoi(getenv("AICG_CONV_WS")) : 1;
+    const bool off_ok = (long)p.BKC * p.x_sc + (long)p.H * p.x_sh < (1L << 31) && (long)p.taps * p.Cin_pad * p.Mpad < (1L << 31);
+    if (ws && off_ok) {  // wave-specialised form (KSTAGE rows per stage, double-buffered)
+        const int xrw = xr <= 8 ? 8 : 12;
+        const size_t ldsw = (size_t)(2 * xrw * 256 + 2 * WsGeom<BM, KSTAGE>::WS_ELEMS) * sizeof(float);
+        if (xrw == 8) {
+            auto kern = conv_ws16_kernel<BM, 8, KSTAGE>;
+            if (ldsw > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
+            hipLaunchKernelGGL(kern, grid, dim3(512), ldsw, stream, p);
+        } else {
+            auto kern = conv_ws16_kernel<BM, 12, KSTAGE>;
+            if (ldsw > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
+            hipLaunchKernelGGL(kern, grid, dim3(512), ldsw, stream, p);
+        }
+        return check_launch("conv_ws16_kernel");
+    }
     if (xr <= 8) {
         auto kern = conv_mfma16_kernel<BM, 8>;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
