@@ -1,6 +1,25 @@
 // Error plumbing and version entry points of the C ABI (include/aicg.h).
 #include "common.h"
 
+#include <mutex>
+#include <unordered_map>
+
+namespace aicg {
+void allow_dynamic_lds(const void* kernel, size_t bytes) {
+    if (bytes <= 64 * 1024) return;
+    static std::mutex mu;
+    static std::unordered_map<const void*, size_t> granted;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& g = granted[kernel];
+    if (g >= bytes) return;
+    // grant the whole 160 KB of a gfx950 CU at once: one runtime call per kernel for the lifetime of the process
+    const size_t want = 160 * 1024;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want) == hipSuccess) g = want;
+    else (void)hipGetLastError();  // the launch itself reports the failure
+}
+}  // namespace aicg
+
+
 namespace aicg {
 
 static thread_local char g_err[512] = "";

@@ -19,6 +19,10 @@ inline int check_launch(const char* what) {
     return AICG_OK;
 }
 
+// Raise a kernel's dynamic-LDS limit above the 64 KB default, once per kernel (hipFuncSetAttribute is a blocking runtime
+// call: issued per launch it serialises streams -- it stalled pipeline()'s f0 side stream against the main stream).
+void allow_dynamic_lds(const void* kernel, size_t bytes);
+
 __host__ __device__ inline int idiv_up(int a, int b) { return (a + b - 1) / b; }
 __host__ __device__ inline long ldiv_up(long a, long b) { return (a + b - 1) / b; }
 __host__ __device__ inline int imin(int a, int b) { return a < b ? a : b; }

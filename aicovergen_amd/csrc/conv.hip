@@ -826,7 +826,7 @@ template <int BM, int BN, int WM, int WN, int XR>
 static int launch_conv_xr(ConvArgs& p, hipStream_t stream, size_t lds) {
     auto kern = conv_mfma_kernel<BM, BN, WM, WN, XR>;
     if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        allow_dynamic_lds((const void*)kern, lds);
     const long gx = (long)p.N * p.tiles_h * p.tiles_w;
     if (gx > 2147483647L) return fail(AICG_E_SHAPE, "conv: too many output tiles");
     dim3 grid((unsigned)gx, (unsigned)idiv_up(p.Cout_g, BM), (unsigned)p.groups);
@@ -929,11 +929,11 @@ static int launch_conv_ws(ConvArgs& p, hipStream_t stream) {
     dim3 block(64 * (WM * WN + 4));
     if (xr == 8) {
         auto kern = conv_ws_kernel<BM, BN, WM, WN, 8, KS>;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        allow_dynamic_lds((const void*)kern, lds);
         hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
     } else {
         auto kern = conv_ws_kernel<BM, BN, WM, WN, 12, KS>;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        allow_dynamic_lds((const void*)kern, lds);
         hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
     }
     return check_launch("conv_ws_kernel");
@@ -977,22 +977,22 @@ static int launch_conv16(ConvArgs& p, hipStream_t stream) {
         const size_t ldsw = (size_t)(2 * xrw * 256 + 2 * WsGeom<BM, KSTAGE>::WS_ELEMS) * sizeof(float);
         if (xrw == 8) {
             auto kern = conv_ws16_kernel<BM, 8, KSTAGE>;
-            if (ldsw > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
+            allow_dynamic_lds((const void*)kern, ldsw);
             hipLaunchKernelGGL(kern, grid, dim3(512), ldsw, stream, p);
         } else {
             auto kern = conv_ws16_kernel<BM, 12, KSTAGE>;
-            if (ldsw > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsw);
+            allow_dynamic_lds((const void*)kern, ldsw);
             hipLaunchKernelGGL(kern, grid, dim3(512), ldsw, stream, p);
         }
         return check_launch("conv_ws16_kernel");
     }
     if (xr <= 8) {
         auto kern = conv_mfma16_kernel<BM, 8>;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        allow_dynamic_lds((const void*)kern, lds);
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
     } else {
         auto kern = conv_mfma16_kernel<BM, 12>;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        allow_dynamic_lds((const void*)kern, lds);
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
     }
     return check_launch("conv_mfma16_kernel");

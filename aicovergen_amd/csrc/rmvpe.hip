@@ -329,7 +329,7 @@ extern "C" int aicg_gru_bidir(const float* gi, const float* whh_t, const float* 
         constexpr int KR = 96, KL = 48;
         const size_t lds = (size_t)(4 * 256 + KL * 768) * sizeof(float);
         auto kern = gru_kernel<256, KR, KL>;
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        allow_dynamic_lds((const void*)kern, lds);
         hipLaunchKernelGGL(kern, dim3(2), dim3(384), lds, (hipStream_t)stream, gi, whh_t, bhh, out, (long)T);
     } else if (hidden == 64) {
         constexpr int KR = 32, KL = 16;
@@ -355,7 +355,7 @@ extern "C" int aicg_gru_bidir_2wg(const float* gi, const float* whh_t, const flo
         constexpr int KR = 208;
         const size_t lds = (size_t)(256 + 384 + (256 - KR) * 384) * sizeof(float);
         auto kern = gru2_kernel<256, KR>;
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        allow_dynamic_lds((const void*)kern, lds);
         hipLaunchKernelGGL(kern, dim3(4), dim3(384), lds, (hipStream_t)stream, gi, whh_t, bhh, out, (long)T, xb, err);
     } else if (hidden == 64) {
         constexpr int KR = 48;
@@ -471,7 +471,7 @@ extern "C" int aicg_crepe_viterbi(const float* probs, const int* seq_len, float*
         return aicg::fail(AICG_E_SHAPE, "aicg_crepe_viterbi: bad bin range");
     if (n_seq <= 0) return AICG_OK;
     const size_t lds = (size_t)(2 * 384 + 384 * 24) * sizeof(double);
-    (void)hipFuncSetAttribute((const void*)aicg::crepe_viterbi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    allow_dynamic_lds((const void*)aicg::crepe_viterbi_kernel, lds);
     hipLaunchKernelGGL(aicg::crepe_viterbi_kernel, dim3((unsigned)n_seq), dim3(384), lds, (hipStream_t)stream, probs, seq_len,
                        logp_scratch, (unsigned short*)ptr_scratch, (long*)bins_out, n_bins, max_steps, bin_lo, bin_hi);
     return aicg::check_launch("crepe_viterbi_kernel");

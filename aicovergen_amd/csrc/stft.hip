@@ -267,7 +267,7 @@ extern "C" int aicg_stft(const float* x, float* out, const float* window, const 
     const long total = (long)n_sig * n_frames;
     const unsigned grid = (unsigned)((total + p.fr_per_block - 1) / p.fr_per_block);
     if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)stft_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        allow_dynamic_lds((const void*)stft_kernel, lds);
     hipLaunchKernelGGL(stft_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
     return check_launch("stft_kernel");
 }
@@ -288,7 +288,7 @@ extern "C" int aicg_istft_frames(const float* spec, float* frames, const float* 
     const long total = (long)n_sig * n_frames;
     const unsigned grid = (unsigned)((total + p.fr_per_block - 1) / p.fr_per_block);
     if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)istft_frames_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        allow_dynamic_lds((const void*)istft_frames_kernel, lds);
     hipLaunchKernelGGL(istft_frames_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
     return check_launch("istft_frames_kernel");
 }

@@ -445,6 +445,18 @@ def avgpool2x2(x):
 GRU_TWO_WORKGROUPS = os.environ.get("AICG_GRU_2WG", "1") != "0"
 
 
+_gru_pending = []
+
+
+def gru_check_pending():
+    """Raise if any two-workgroup GRU launch since the last call reported a partner-exchange timeout.  Call after the
+    stream that ran them has been drained (RMVPE does, right after copying f0 to the host)."""
+    flags, _gru_pending[:] = list(_gru_pending), []
+    for f in flags:
+        if int(f.item()) != 0:
+            raise RuntimeError("aicg_gru_bidir_2wg: partner workgroup exchange timed out")
+
+
 def gru_bidir(gi, whh_t, bhh, hidden, two_workgroups=None):
     """gi: (6*hidden, T) channel-major input projections -> (2*hidden, T).  Default: the two-workgroup-per-direction
     kernel (all of W_hh on chip); `two_workgroups=False` (or AICG_GRU_2WG=0) selects the single-workgroup kernel."""
@@ -455,8 +467,9 @@ def gru_bidir(gi, whh_t, bhh, hidden, two_workgroups=None):
     if GRU_TWO_WORKGROUPS if two_workgroups is None else two_workgroups:
         scratch = torch.empty(32 * hidden + 64, dtype=torch.uint8, device=gi.device)
         _lib.call("aicg_gru_bidir_2wg", _ptr(gi), _ptr(whh_t), _ptr(bhh), _ptr(out), hidden, t, _ptr(scratch), _stream(gi))
-        if int(scratch[32 * hidden: 32 * hidden + 4].view(torch.int32).item()) != 0:
-            raise RuntimeError("aicg_gru_bidir_2wg: partner workgroup exchange timed out")
+        # the kernel's exchange-timeout flag is read back lazily (gru_check_pending): an .item() here would park the host
+        # until the recurrence ends, which is exactly the time pipeline() wants to spend queueing HuBERT work
+        _gru_pending.append(scratch[32 * hidden: 32 * hidden + 4].view(torch.int32))
         return out
     _lib.call("aicg_gru_bidir", _ptr(gi), _ptr(whh_t), _ptr(bhh), _ptr(out), hidden, t, _stream(gi))
     return out

@@ -186,14 +186,24 @@ class RMVPE:
     def decode(self, hidden, thred=0.03):
         """hidden: (T, 360) numpy or tensor -> f0 float64 numpy (src/rmvpe.py:359-364)."""
         h = torch.as_tensor(hidden).to(self.device)
-        return self._decode_device(h, thred)[1].cpu().numpy()
+        out = self._decode_device(h, thred)[1].cpu().numpy()
+        ops.gru_check_pending()
+        return out
 
     def to_local_average_cents(self, salience, thred=0.05):
         s = torch.as_tensor(salience).to(self.device)
         return self._decode_device(s, thred)[0].cpu().numpy()
 
-    def infer_from_audio(self, audio, thred=0.03):
-        audio = torch.from_numpy(np.asarray(audio)).float().to(self.device).unsqueeze(0)
+    def infer_from_audio_device(self, audio, thred=0.03):
+        """infer_from_audio without the final device->host copy: everything is queued on the current stream."""
+        if not torch.is_tensor(audio):
+            audio = torch.from_numpy(np.asarray(audio))
+        audio = audio.float().to(self.device).unsqueeze(0)
         mel = self.mel_extractor(audio, center=True)
         hidden = self.mel2hidden(mel)
-        return self._decode_device(hidden[0], thred)[1].cpu().numpy()
+        return self._decode_device(hidden[0], thred)[1]
+
+    def infer_from_audio(self, audio, thred=0.03):
+        f0 = self.infer_from_audio_device(audio, thred).cpu().numpy()
+        ops.gru_check_pending()
+        return f0

@@ -81,16 +81,23 @@ class VC(object):
         print("Initiating prediction with a crepe_hop_length of: " + str(hop_length))
         return crepe.mangio_crepe_f0(self.model_crepe[model], x, p_len, hop_length, dither=dither)
 
-    def get_f0(self, input_audio_path, x, p_len, f0_up_key, f0_method, filter_radius, crepe_hop_length, inp_f0=None):
-        """-> (f0_coarse int64 (n,), f0 float64 (n,)) (reference :262-370)."""
+    def _rmvpe(self):
+        if not hasattr(self, "model_rmvpe"):
+            from .rmvpe import RMVPE
+            self.model_rmvpe = RMVPE(self.rmvpe_path, is_half=self.is_half, device=self.device)
+        return self.model_rmvpe
+
+    def get_f0(self, input_audio_path, x, p_len, f0_up_key, f0_method, filter_radius, crepe_hop_length, inp_f0=None,
+               _raw_f0=None):
+        """-> (f0_coarse int64 (n,), f0 float64 (n,)) (reference :262-370).  `_raw_f0` (internal): the estimator's output
+        when pipeline() has already run it on a side stream."""
         f0_min, f0_max = 50, 1100
         f0_mel_min = 1127 * np.log(1 + f0_min / 700)
         f0_mel_max = 1127 * np.log(1 + f0_max / 700)
-        if f0_method == "rmvpe":
-            if not hasattr(self, "model_rmvpe"):
-                from .rmvpe import RMVPE
-                self.model_rmvpe = RMVPE(self.rmvpe_path, is_half=self.is_half, device=self.device)
-            f0 = self.model_rmvpe.infer_from_audio(x, thred=0.03)
+        if _raw_f0 is not None:
+            f0 = _raw_f0
+        elif f0_method == "rmvpe":
+            f0 = self._rmvpe().infer_from_audio(x, thred=0.03)
         elif f0_method in ("mangio-crepe", "mangio-crepe-tiny"):
             f0 = self.get_f0_crepe_computation(x, f0_min, f0_max, p_len, crepe_hop_length,
                                                "tiny" if f0_method.endswith("tiny") else "full")
@@ -118,43 +125,13 @@ class VC(object):
         """One padded chunk -> float32 waveform at tgt_sr (reference :372-472).  `noise` = (noise_z, noise_src)
         replaces the synthesizer's random draws (parity tests); `keep_on_device` returns the waveform as a device
         tensor instead of the reference's numpy array (used by pipeline(), which post-processes on the device)."""
-        feats = torch.from_numpy(np.ascontiguousarray(audio0)).float()
-        if feats.dim() == 2:
-            feats = feats.mean(-1)
-        assert feats.dim() == 1, feats.dim()
-        feats = feats.view(1, -1)
-        padding_mask = torch.zeros(feats.shape, dtype=torch.bool)
         t0 = ttime()
-        logits = model.extract_features(source=feats.to(self.device), padding_mask=padding_mask,
-                                        output_layer=9 if version == "v1" else 12)
-        feats = model.final_proj(logits[0]) if version == "v1" else logits[0]
-        use_protect = protect < 0.5 and pitch is not None and pitchf is not None
-        feats0 = feats.clone() if use_protect else None
-        if index is not None and big_npy is not None and index_rate != 0:
-            npy = feats[0].cpu().numpy().astype("float32")
-            score, ix = index.search(npy, k=8)
-            weight = np.square(1 / score)
-            weight /= weight.sum(axis=1, keepdims=True)
-            npy = np.sum(big_npy[ix] * np.expand_dims(weight, axis=2), axis=1)
-            feats = torch.from_numpy(npy.astype("float32")).unsqueeze(0).to(self.device) * index_rate + (1 - index_rate) * feats
+        feats, feats0 = self._vc_features(model, audio0, index, big_npy, index_rate, version,
+                                          protect < 0.5 and pitch is not None and pitchf is not None)
         if self._sync():
             torch.cuda.synchronize()
         t1 = ttime()
-        p_len = audio0.shape[0] // self.window
-        if 2 * feats.shape[1] < p_len:
-            p_len = 2 * feats.shape[1]
-        if pitch is not None and pitchf is not None:
-            pitch = pitch[:, :p_len]
-            pitchf = pitchf[:, :p_len]
-        # nearest x2 upsample + protect blend, written channel-major for the synthesizer (:433-452)
-        phone_ct = ops.feats_prepare(feats[0], p_len, feats0[0] if use_protect else None,
-                                     pitchf[0].float() if use_protect else None, protect)
-        nz, ns = noise if noise is not None else (None, None)
-        lens = torch.tensor([p_len], device=self.device).long()
-        if pitch is not None and pitchf is not None:
-            o = net_g.infer(None, lens, pitch, pitchf, sid, noise_z=nz, noise_src=ns, phone_ct=phone_ct)[0]
-        else:
-            o = net_g.infer(None, lens, sid, noise_z=nz, noise_src=ns, phone_ct=phone_ct)[0]
+        o = self._vc_synth(net_g, sid, audio0.shape[0], feats, feats0, pitch, pitchf, protect, noise)
         if keep_on_device:
             if self._sync():
                 torch.cuda.synchronize()
@@ -165,6 +142,46 @@ class VC(object):
         times[0] += t1 - t0
         times[2] += t2 - t1
         return audio1
+
+    def _vc_features(self, model, audio0, index, big_npy, index_rate, version, use_protect):
+        """HuBERT features of one chunk (+ optional faiss index mix), reference :379-431.  Needs no pitch."""
+        # audio0: host array (reference contract) or a slice of the track already resident on the device
+        feats = audio0.float() if torch.is_tensor(audio0) else torch.from_numpy(np.ascontiguousarray(audio0)).float()
+        if feats.dim() == 2:
+            feats = feats.mean(-1)
+        assert feats.dim() == 1, feats.dim()
+        feats = feats.view(1, -1)
+        padding_mask = torch.zeros(feats.shape, dtype=torch.bool)
+        logits = model.extract_features(source=feats.to(self.device), padding_mask=padding_mask,
+                                        output_layer=9 if version == "v1" else 12)
+        feats = model.final_proj(logits[0]) if version == "v1" else logits[0]
+        feats0 = feats.clone() if use_protect else None
+        if index is not None and big_npy is not None and index_rate != 0:
+            npy = feats[0].cpu().numpy().astype("float32")
+            score, ix = index.search(npy, k=8)
+            weight = np.square(1 / score)
+            weight /= weight.sum(axis=1, keepdims=True)
+            npy = np.sum(big_npy[ix] * np.expand_dims(weight, axis=2), axis=1)
+            feats = torch.from_numpy(npy.astype("float32")).unsqueeze(0).to(self.device) * index_rate + (1 - index_rate) * feats
+        return feats, feats0
+
+    def _vc_synth(self, net_g, sid, n_samples, feats, feats0, pitch, pitchf, protect, noise):
+        """Features (+ pitch) of one chunk -> synthesizer output (1, 1, T) on the device, reference :433-466."""
+        p_len = n_samples // self.window
+        if 2 * feats.shape[1] < p_len:
+            p_len = 2 * feats.shape[1]
+        if pitch is not None and pitchf is not None:
+            pitch = pitch[:, :p_len]
+            pitchf = pitchf[:, :p_len]
+        use_protect = feats0 is not None
+        # nearest x2 upsample + protect blend, written channel-major for the synthesizer (:433-452)
+        phone_ct = ops.feats_prepare(feats[0], p_len, feats0[0] if use_protect else None,
+                                     pitchf[0].float() if use_protect else None, protect)
+        nz, ns = noise if noise is not None else (None, None)
+        lens = torch.tensor([p_len], device=self.device).long()
+        if pitch is not None and pitchf is not None:
+            return net_g.infer(None, lens, pitch, pitchf, sid, noise_z=nz, noise_src=ns, phone_ct=phone_ct)[0]
+        return net_g.infer(None, lens, sid, noise_z=nz, noise_src=ns, phone_ct=phone_ct)[0]
 
     def _sync(self):
         return torch.cuda.is_available() and str(self.device).startswith("cuda")
@@ -235,22 +252,61 @@ class VC(object):
             except Exception:
                 traceback.print_exc()
         sid = torch.tensor(sid, device=self.device).unsqueeze(0).long()
-        pitch, pitchf = None, None
-        if if_f0 == 1:
-            pitch, pitchf = self.get_f0(input_audio_path, audio_pad, p_len, f0_up_key, f0_method, filter_radius,
-                                        crepe_hop_length, inp_f0)
-            pitch = torch.tensor(pitch[:p_len], device=self.device).unsqueeze(0).long()
-            pitchf = torch.tensor(pitchf[:p_len], device=self.device).unsqueeze(0).float()
-        if self._sync():
-            torch.cuda.synchronize()
-        t2 = ttime()
-        times[1] += t2 - t1
         bounds = self.chunk_bounds(audio_pad, opt_ts)
         rank, world = adist.world(group)
+        mine = [ci for ci in range(len(bounds)) if ci % world == rank]
+        pitch, pitchf = None, None
+        use_protect = protect < 0.5 and if_f0 == 1
+
+        def run_f0(raw=None):
+            pc, pcf = self.get_f0(input_audio_path, audio_pad, p_len, f0_up_key, f0_method, filter_radius,
+                                  crepe_hop_length, inp_f0, _raw_f0=raw)
+            return (torch.tensor(pc[:p_len], device=self.device).unsqueeze(0).long(),
+                    torch.tensor(pcf[:p_len], device=self.device).unsqueeze(0).float())
+
+        # The f0 estimate does not depend on the HuBERT features and RMVPE's recurrent part occupies a handful of CUs, so on
+        # the GPU its kernels are queued on a side stream first and the feature extraction of every chunk runs on the main
+        # stream on top of them; the synthesizer passes start once both are done.  Everything is enqueued from this thread
+        # (a helper thread fights the launch loop for the GIL).  AICG_OVERLAP_F0=0 restores the reference's serial order
+        # (f0, then per chunk: features, synthesis).
+        overlap = (if_f0 == 1 and f0_method == "rmvpe" and self._sync()
+                   and os.environ.get("AICG_OVERLAP_F0", "1") != "0")
+        feats_of = {}
+        f0_wait = 0.0
+        if overlap:
+            main = torch.cuda.current_stream(self.device)
+            side = torch.cuda.Stream(device=self.device)
+            # one upload of the padded track: a pageable host->device copy on the default stream waits for the whole device,
+            # side stream included, so the chunk loop below must not issue any
+            pad_dev = torch.from_numpy(np.ascontiguousarray(audio_pad)).to(self.device).float()
+            side.wait_stream(main)
+            tf0 = ttime()
+            with torch.cuda.stream(side):
+                f0_dev = self._rmvpe().infer_from_audio_device(pad_dev, thred=0.03)
+            for ci in mine:
+                s, e = bounds[ci]
+                feats_of[ci] = self._vc_features(model, pad_dev[s:e], index, big_npy, index_rate, version, use_protect)
+            main.synchronize()
+            tf1 = ttime()
+            side.synchronize()
+            main.wait_stream(side)
+            pitch, pitchf = run_f0(f0_dev.cpu().numpy())
+            ops.gru_check_pending()
+            del f0_dev
+            t2 = ttime()
+            f0_wait = t2 - tf1
+            times[0] += tf1 - tf0
+            times[1] += t2 - tf0  # the f0 branch's own wall time (it overlaps times[0])
+        else:
+            if if_f0 == 1:
+                pitch, pitchf = run_f0()
+            if self._sync():
+                torch.cuda.synchronize()
+            t2 = ttime()
+            times[1] += t2 - t1
         pieces = {}
-        for ci, (s, e) in enumerate(bounds):
-            if ci % world != rank:
-                continue
+        for ci in mine:
+            s, e = bounds[ci]
             last = ci == len(bounds) - 1
             if if_f0 == 1:
                 pe = None if last else (e - self.window) // self.window
@@ -258,8 +314,15 @@ class VC(object):
             else:
                 pc = pcf = None
             noise = noise_fn(ci, s, e) if noise_fn is not None else None
-            out = self.vc(model, net_g, sid, audio_pad[s:e], pc, pcf, times, index, big_npy, index_rate, version, protect,
-                          noise=noise, keep_on_device=True)
+            if overlap:
+                ts0 = ttime()
+                feats, feats0 = feats_of.pop(ci)
+                out = self._vc_synth(net_g, sid, e - s, feats, feats0, pc, pcf, protect, noise)[0, 0]
+                torch.cuda.synchronize()
+                times[2] += ttime() - ts0
+            else:
+                out = self.vc(model, net_g, sid, audio_pad[s:e], pc, pcf, times, index, big_npy, index_rate, version, protect,
+                              noise=noise, keep_on_device=True)
             pieces[ci] = out[self.t_pad_tgt: -self.t_pad_tgt]
         tc1 = ttime()
         pieces = adist.gather_pieces(pieces, len(bounds), self.device, group)
@@ -283,7 +346,9 @@ class VC(object):
             max_int16 /= audio_max
         audio_opt = ops.to_int16(audio_opt, max_int16).cpu().numpy()
         # wall-clock split of this call (host pre-processing, f0, chunk loop, join + host post-processing)
-        self.last_profile = {"plan_s": t1 - tp0, "f0_s": t2 - t1, "chunks_s": tc1 - t2, "post_s": ttime() - tc1}
+        # (overlapped schedule: f0_s = features of every chunk with the f0 branch underneath, f0_wait_s of it spent waiting for f0)
+        self.last_profile = {"plan_s": t1 - tp0, "f0_s": t2 - t1, "chunks_s": tc1 - t2, "post_s": ttime() - tc1,
+                             "f0_wait_s": f0_wait, "overlap_f0": float(bool(overlap))}
         return audio_opt
 
 

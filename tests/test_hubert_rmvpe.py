@@ -152,4 +152,5 @@ def test_gru_kernels_match_torch(dev, hidden, T):
     bhh = torch.cat([sd["fc.0.gru.bias_hh_l0"], sd["fc.0.gru.bias_hh_l0_reverse"]])
     for two in (False, True):
         got = ops.gru_bidir(dev.t(gi), dev.t(whh_t.contiguous()), dev.t(bhh), hidden, two_workgroups=two)
+        ops.gru_check_pending()
         assert rel_rms(got, ref) < 1e-5, "two_workgroups=%s" % two
