@@ -40,13 +40,16 @@ def test_conv_transpose2d(dev):
     assert rel_rms(ops.conv_transpose(dev.t(x), pt), F.conv_transpose2d(x, w, b, stride=2)) < 1e-5
 
 
-def test_layernorm_ct(dev):
+@pytest.mark.parametrize("C,with_res", [(192, True), (768, True), (1000, False), (1100, True)])
+def test_layernorm_ct(dev, C, with_res):
+    """Channel LayerNorm of (N, C, T): the register-resident kernel (C <= 256 / 768 / 1024) and the strided fallback (C = 1100),
+    ragged T (not a multiple of the 32-column tile)."""
     torch.manual_seed(3)
-    T = 3000 if dev.big else 130
-    x, r = torch.randn(2, 192, T), torch.randn(2, 192, T)
-    g, b = torch.rand(192) + 0.5, torch.randn(192)
-    y = ops.layernorm_ct(dev.t(x), dev.t(g), dev.t(b), res=dev.t(r))
-    ref = F.layer_norm((x + r).transpose(1, 2), (192,), g, b, 1e-5).transpose(1, 2)
+    T = 3001 if dev.big else 131
+    x, r = torch.randn(2, C, T) + 0.3, torch.randn(2, C, T)
+    g, b = torch.rand(C) + 0.5, torch.randn(C)
+    y = ops.layernorm_ct(dev.t(x), dev.t(g), dev.t(b), res=dev.t(r) if with_res else None)
+    ref = F.layer_norm((x + r if with_res else x).transpose(1, 2), (C,), g, b, 1e-5).transpose(1, 2)
     assert rel_rms(y, ref) < 1e-5
 
 
