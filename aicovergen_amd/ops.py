@@ -187,12 +187,13 @@ class ConvProfile:
     def __init__(self):
         self.events = []
         self.flops = 0.0
+        self.bytes = 0.0  # algorithmic HBM bytes: input + packed weights + output (+ residual / accumulate reads), each once
         self.launches = 0
 
     def summary(self):
         torch.cuda.synchronize()
         ms = sum(a.elapsed_time(b) for a, b in self.events)
-        return {"launches": self.launches, "flops": self.flops, "ms": ms,
+        return {"launches": self.launches, "flops": self.flops, "ms": ms, "bytes": self.bytes,
                 "tflops": (self.flops / (ms * 1e-3) / 1e12) if ms > 0 else 0.0}
 
 
@@ -248,6 +249,8 @@ def conv(x, pc, res=None, out=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NON
         e1.record()
         prof.events.append((e0, e1))
         prof.flops += 2.0 * n * pc.cout * (pc.cin // pc.groups) * pc.kh * pc.kw * ho * wo
+        prof.bytes += 4.0 * (n * c * h * w + pc.cout * (pc.cin // pc.groups) * pc.kh * pc.kw
+                             + n * pc.cout * ho * wo * (1 + (r4 is not None) + bool(accumulate)))
         prof.launches += 1
     return out
 

@@ -96,6 +96,19 @@ def cpu_baseline(seconds_rvc=4.0):
                       % (seconds_rvc, mdx_cost, rvc_cost)}
 
 
+def pmc_traffic_per_launch():
+    """HBM bytes per conv launch from the committed rocprofv3 PMC passes of this same command (profiles/r01_summary.json:
+    FETCH_SIZE + WRITE_SIZE, KiB units, summed over the conv kernels, uncorrected -- see DESIGN.md section 5); None when the
+    summary is absent.  The counters cannot be collected inside the timed run."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_summary.json")
+    try:
+        s = json.load(open(path))
+        f, w = s["FETCH_SIZE"], s["WRITE_SIZE"]
+        return (f["conv_kernels_sum"] / f["conv_kernels_calls"] + w["conv_kernels_sum"] / w["conv_kernels_calls"]) * 1024.0
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -176,9 +189,11 @@ def main():
                                                   "synth": stage[2] / args.steps},
                        "wall_split_seconds_per_step": split},
             "roofline": {"bound": "mfma", "achieved": conv["tflops"], "peak": 157.3, "unit": "TFLOP/s",
-                         "frac": conv["tflops"] / 157.3, "traffic": None, "kernel": "conv_mfma_kernel (fp32 MFMA implicit GEMM)",
+                         "frac": conv["tflops"] / 157.3, "traffic": pmc_traffic_per_launch(),
+                         "kernel": "conv_ws_kernel family (fp32 MFMA implicit GEMM: conv_ws / conv_ws16 / conv_mfma / conv_mfma16)",
                          "launches_per_step": conv["launches"] / args.steps,
                          "algorithmic_tflop_per_step": conv["flops"] / args.steps / 1e12,
+                         "algorithmic_bytes_per_launch": conv["bytes"] / max(1, conv["launches"]),
                          "kernel_ms_per_step": conv["ms"] / args.steps},
         }
         if world == 1 and not args.no_cpu_baseline:
