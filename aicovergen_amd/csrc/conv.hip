@@ -1072,10 +1072,25 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
     if (ws) {
         int rc = 1;
         if (BM == 160 && blocks(160, 128) >= want) rc = launch_conv_ws<160, 128, 1, 4, 32>(p, st);
-        else if (BM == 128 && blocks(128, 128) >= want) rc = (ws == 3) ? launch_conv_ws<128, 128, 2, 2, 32>(p, st) : launch_conv_ws<128, 128, 2, 4, 64>(p, st);
+        else if (BM == 128 && blocks(128, 128) >= want) {
+            // >= 2 M tiles of 128: four-consumer 64-row tiles (two workgroups per CU overlap their prologue / epilogue) measured
+            // 7 % faster than the one-per-CU 128 x 128 shape on the 256-channel vocoder stage; a single 128-row tile keeps the latter
+            static const int bm128e = getenv("AICG_CONV_BM128") ? atoi(getenv("AICG_CONV_BM128")) : 0;
+            const bool use64 = bm128e ? bm128e == 64 : M >= 256;
+            rc = use64 ? launch_conv_ws<64, 128, 2, 2, 64>(p, st) : launch_conv_ws<128, 128, 2, 4, 64>(p, st);
+        }
         else if (BM == 96 && blocks(96, 128) >= want) rc = launch_conv_ws<96, 128, 1, 4, 64>(p, st);
         else if (M > 32 && blocks(64, 128) >= want) rc = launch_conv_ws<64, 128, 2, 2, 64>(p, st);
         if (rc <= 0) return rc;
+        // small problems (few output positions: HuBERT / enc_p / flow GEMMs) and 32-channel layers: the same kernel on smaller tiles
+        static const int smallws = getenv("AICG_CONV_SMALLWS") ? atoi(getenv("AICG_CONV_SMALLWS")) : 1;
+        if (smallws) {
+            if (M > 32) {
+                if (!(blocks(64, 128) >= want) && (blocks(64, 64) >= want || M > 64)) rc = launch_conv_ws<64, 64, 2, 2, 64>(p, st);
+            } else if (blocks(32, 256) >= want) rc = launch_conv_ws<32, 256, 1, 4, 64>(p, st);
+            else rc = launch_conv_ws<32, 128, 1, 4, 64>(p, st);
+            if (rc <= 0) return rc;
+        }
     }
     if (BM == 160 && blocks(160, 128) >= want) return launch_conv<160, 128, 1, 4>(p, st);
     static const bool eight = getenv("AICG_CONV_8WAVE") ? atoi(getenv("AICG_CONV_8WAVE")) != 0 : true;
