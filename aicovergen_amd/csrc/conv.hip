@@ -19,6 +19,7 @@
 
 #include "common.h"
 
+#include <cstdint>
 #include <cstdlib>
 
 namespace aicg {
@@ -819,6 +820,75 @@ __global__ void __launch_bounds__(512, 4) conv_ws16_kernel(ConvArgs p) {
     if (interior) epilogue(std::true_type{}); else epilogue(std::false_type{});
 }
 
+// ---- pointwise streaming kernel -------------------------------------------------------------------------------------------
+// 1x1 layers with at most 8 input or 8 output channels (MDX-Net's 4 -> 48 stem and 48 -> 4 head: 2.4 GB of activations each,
+// 2 x 4 x 48 flop per position) are pure HBM streams; as MFMA tiles they ran at 0.45 TB/s.  One thread = 4 consecutive positions
+// (float4); the weights are wave-uniform scalar loads from the packed [Cin_pad][Mpad] image.
+template <bool FEW_IN>
+__global__ void __launch_bounds__(256) conv_pointwise_kernel(ConvArgs p) {
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;   // float4 index within one image (H * W / 4 of them)
+    const long per_img = (long)p.Ho * (p.Wo >> 2);
+    if (q >= per_img) return;
+    const int n = blockIdx.y;
+    const int h = (int)(q / (p.Wo >> 2));
+    const int w4 = (int)(q - (long)h * (p.Wo >> 2)) * 4;
+    const float* xp = p.x + (long)n * p.x_sn + (long)h * p.x_sh + w4;
+    float* yp = p.y + (long)n * p.y_sn + (long)h * p.y_sh + w4;
+    const float* rp = p.res ? p.res + (long)n * p.r_sn + (long)h * p.r_sh + w4 : nullptr;
+    auto finish = [&](float4 a, int co) __attribute__((always_inline)) {
+        if (rp) {
+            const float4 r = *reinterpret_cast<const float4*>(rp + (long)co * p.r_sc);
+            if (p.res_first) { a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w; }
+            a.x = apply_act(a.x, p.act, p.act_slope); a.y = apply_act(a.y, p.act, p.act_slope);
+            a.z = apply_act(a.z, p.act, p.act_slope); a.w = apply_act(a.w, p.act, p.act_slope);
+            if (!p.res_first) { a.x += r.x; a.y += r.y; a.z += r.z; a.w += r.w; }
+        } else {
+            a.x = apply_act(a.x, p.act, p.act_slope); a.y = apply_act(a.y, p.act, p.act_slope);
+            a.z = apply_act(a.z, p.act, p.act_slope); a.w = apply_act(a.w, p.act, p.act_slope);
+        }
+        a.x *= p.out_scale; a.y *= p.out_scale; a.z *= p.out_scale; a.w *= p.out_scale;
+        *reinterpret_cast<float4*>(yp + (long)co * p.y_sc) = a;
+    };
+    if (FEW_IN) {
+        float4 xv[8];
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci)
+            xv[ci] = ci < p.Cin_g ? *reinterpret_cast<const float4*>(xp + (long)ci * p.x_sc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int co = 0; co < p.Cout_g; ++co) {
+            const float b = p.bias ? p.bias[co] : 0.f;
+            float4 a = make_float4(b, b, b, b);
+#pragma unroll
+            for (int ci = 0; ci < 8; ++ci) {
+                if (ci < p.Cin_g) {
+                    const float wv = p.w[ci * p.Mpad + co];
+                    a.x += wv * xv[ci].x; a.y += wv * xv[ci].y; a.z += wv * xv[ci].z; a.w += wv * xv[ci].w;
+                }
+            }
+            finish(a, co);
+        }
+    } else {
+        float4 a[8];
+#pragma unroll
+        for (int co = 0; co < 8; ++co) {
+            const float b = (p.bias && co < p.Cout_g) ? p.bias[co] : 0.f;
+            a[co] = make_float4(b, b, b, b);
+        }
+        for (int ci = 0; ci < p.Cin_g; ++ci) {
+            const float4 xv = *reinterpret_cast<const float4*>(xp + (long)ci * p.x_sc);
+#pragma unroll
+            for (int co = 0; co < 8; ++co) {
+                if (co < p.Cout_g) {
+                    const float wv = p.w[ci * p.Mpad + co];
+                    a[co].x += wv * xv.x; a[co].y += wv * xv.y; a[co].z += wv * xv.z; a[co].w += wv * xv.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < 8; ++co)
+            if (co < p.Cout_g) finish(a[co], co);
+    }
+}
+
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static unsigned div_mul(int d) { return (unsigned)((0x100000000ULL + (unsigned long long)d - 1) / (unsigned long long)d); }
 
@@ -1039,6 +1109,25 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
     p.Mpad = idiv_up(p.Cout_g, 32) * 32;
     p.Cin_pad = idiv_up(p.Cin_g, 32) * 32;
     p.w_group_stride = (long)p.taps * p.Cin_pad * p.Mpad;
+
+    // pointwise streaming form: 1x1, unit stride, no padding, <= 8 channels on one side, float4-aligned rows
+    {
+        static const bool pointwise = getenv("AICG_CONV_POINTWISE") ? atoi(getenv("AICG_CONV_POINTWISE")) != 0 : true;
+        const bool few_in = p.Cin_g <= 8, few_out = p.Cout_g <= 8;
+        auto al4 = [](long v) { return (v & 3) == 0; };
+        const bool aligned = (Wo & 3) == 0 && al4(p.x_sn) && al4(p.x_sc) && al4(p.x_sh) && al4(p.y_sn) && al4(p.y_sc) && al4(p.y_sh) &&
+                             (!res || (al4(p.r_sn) && al4(p.r_sc) && al4(p.r_sh) && ((uintptr_t)res & 15) == 0)) &&
+                             ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0;
+        if (pointwise && p.taps == 1 && p.groups == 1 && p.sh == 1 && p.sw == 1 && p.ph == 0 && p.pw == 0 && pad_h_end == 0 &&
+            pad_w_end == 0 && (few_in || few_out) && p.Cin_g <= 512 && p.Cout_g <= 512 && p.pre_act == AICG_ACT_NONE &&
+            !p.accumulate && aligned && Ho == p.H && Wo == p.W) {
+            const long per_img = (long)Ho * (Wo >> 2);
+            dim3 grid((unsigned)ldiv_up(per_img, 256), (unsigned)p.N);
+            if (few_in) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_pointwise_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_pointwise_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, p);
+            return check_launch("conv_pointwise_kernel");
+        }
+    }
 
     // tile shape: the BM in {160, 128, 96, 64, 32} with the least padded M (larger BM on ties: one input patch
     // staging feeds more MFMAs), then enough workgroups to fill 256 CUs

@@ -112,3 +112,21 @@ def test_conv_rejects_inconsistent_geometry(dev):
     pc = ops.PackedConv(torch.zeros(8, 8, 3), None, padding=1, device=dev.device)
     with pytest.raises(AssertionError):
         ops.conv(x, pc, out=dev.t(torch.zeros(1, 8, 15)))
+
+
+@pytest.mark.parametrize("n,ci,co,h,w", [(2, 4, 48, 7, 64), (2, 48, 4, 7, 64), (1, 8, 8, 3, 12), (1, 3, 20, 1, 128)])
+def test_pointwise_streaming_form(dev, n, ci, co, h, w):
+    """1x1 layers with <= 8 channels on one side (MDX-Net stem 4 -> 48 and head 48 -> 4) take the float4 streaming kernel:
+    fused bias / residual (either side of the activation) / scale, and channel-slice views on both ends."""
+    torch.manual_seed(ci * 100 + co)
+    if dev.big:
+        h, w = h * 9, w * 8
+    x, wt, b, r = torch.randn(n, ci, h, w), torch.randn(co, ci, 1, 1) * 0.3, torch.randn(co), torch.randn(n, co, h, w)
+    pc = ops.PackedConv(wt, b, device=dev.device)
+    assert rel_rms(ops.conv(dev.t(x), pc, act=ops.ACT_RELU, res=dev.t(r)), F.relu(F.conv2d(x, wt, b)) + r) < 1e-6
+    y = ops.conv(dev.t(x), pc, act=ops.ACT_LRELU, act_slope=0.2, res=dev.t(r), res_before_act=True, out_scale=0.5)
+    assert rel_rms(y, 0.5 * F.leaky_relu(F.conv2d(x, wt, b) + r, 0.2)) < 1e-6
+    big, outbig = dev.t(torch.randn(n, ci + 6, h, w)), dev.t(torch.zeros(n, co + 12, h, w))
+    ops.conv(big[:, 2:2 + ci], pc, out=outbig[:, 8:8 + co])
+    assert rel_rms(outbig[:, 8:8 + co], F.conv2d(big.cpu()[:, 2:2 + ci], wt, b)) < 1e-6
+    assert float(outbig[:, :8].abs().sum()) == 0 and float(outbig[:, 8 + co:].abs().sum()) == 0
