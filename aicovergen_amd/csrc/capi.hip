@@ -42,7 +42,7 @@ int fail(int code, const char* fmt, ...) {
 }  // namespace aicg
 
 extern "C" const char* aicg_last_error(void) { return aicg::g_err; }
-extern "C" int aicg_abi_version(void) { return 1; }
+extern "C" int aicg_abi_version(void) { return 2; }  // 2: aicg_conv_desc gained shuffle / res_mul
 
 // Diagnostic: issue-bound fp32 MFMA loop (no memory traffic) to calibrate the attainable v_mfma_f32_32x32x2_f32 rate
 // of the device the benchmarks run on (clock under load is power-dependent).  Returns nothing useful in `out` beyond

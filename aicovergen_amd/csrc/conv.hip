@@ -41,12 +41,27 @@ struct ConvArgs {
     float out_scale;
     int accumulate;
     int res_first;
+    int shuffle;   // 2: GEMM row m / position (ho, wo) -> y[m >> 2][2 ho + ((m >> 1) & 1)][2 wo + (m & 1)] (k = s = 2 ConvTranspose2d)
+    int res_mul;   // the residual operand multiplies (U-Net multiplicative skip) instead of adding, after the activation
     // derived tiling
     int TW, TWlog2, TH, TH_in, TW_in, TWp, CHS, BKC, BKClog2, TT, tiles_w, tiles_h, nchunk, taps, Mpad, Cin_pad, xs_elems, xs_total;
     unsigned div_chs, div_twp;  // ceil(2^32 / d) multipliers: idx / d == umulhi(idx, mul) for idx * d < 2^32
     long w_group_stride;
     int dbg;  // AICG_CONV_ABLATE bits (profiling only): 1 no global loads, 2 no LDS commit, 4 no barriers, 8 no MFMA loop, 16 no epilogue
 };
+
+// output / residual element of GEMM row cg (= g * Cout_g + m) at position (ho, wo), relative to the image base
+__device__ __forceinline__ long out_index(const ConvArgs& p, int cg, int ho, int wo, long sc, long sh) {
+    return p.shuffle ? (long)(cg >> 2) * sc + (long)(2 * ho + ((cg >> 1) & 1)) * sh + 2 * wo + (cg & 1)
+                     : (long)cg * sc + (long)ho * sh + wo;
+}
+// y = [y_old +] out_scale * (act(v [+ r]) [+ r | * r])
+__device__ __forceinline__ float combine(const ConvArgs& p, float v, float r, float y_old) {
+    if (p.res_first) v += r;
+    v = apply_act(v, p.act, p.act_slope);
+    if (!p.res_first) v = p.res_mul ? v * r : v + r;
+    return v * p.out_scale + y_old;
+}
 
 static constexpr int KSTAGE = 64;  // max K rows of packed weights staged per barrier pair
 
@@ -217,7 +232,6 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 4)) conv_mfm
         const int nl = wn * (TN * 32) + j * 32 + l31;
         const int ho = h0 + (nl >> p.TWlog2), wo = w0 + (nl & (p.TW - 1));
         const bool col_ok = ho < p.Ho && wo < p.Wo;
-        const long y_col = y_base + (long)ho * p.y_sh + wo, r_col = r_base + (long)ho * p.r_sh + wo;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m0 = m_base + wm * (TM * 32) + i * 32 + 4 * half;
@@ -228,19 +242,15 @@ __global__ void __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 2 : 4)) conv_mfm
                 const bool ok = col_ok && m < p.Cout_g;
                 const int co = g * p.Cout_g + m;
                 bv[r] = (ok && p.bias) ? p.bias[co] : 0.f;
-                rv[r] = (ok && p.res) ? p.res[r_col + (long)co * p.r_sc] : 0.f;
-                yv[r] = (ok && p.accumulate) ? p.y[y_col + (long)co * p.y_sc] : 0.f;
+                rv[r] = (ok && p.res) ? p.res[r_base + out_index(p, co, ho, wo, p.r_sc, p.r_sh)] : 0.f;
+                yv[r] = (ok && p.accumulate) ? p.y[y_base + out_index(p, co, ho, wo, p.y_sc, p.y_sh)] : 0.f;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (r & 3) + 8 * (r >> 2);
                 if (!(col_ok && m < p.Cout_g)) continue;
                 const int co = g * p.Cout_g + m;
-                float v = acc[i][j][r] + bv[r];
-                if (p.res_first) v += rv[r];
-                v = apply_act(v, p.act, p.act_slope);
-                if (!p.res_first) v += rv[r];
-                p.y[y_col + (long)co * p.y_sc] = v * p.out_scale + yv[r];
+                p.y[y_base + out_index(p, co, ho, wo, p.y_sc, p.y_sh)] = combine(p, acc[i][j][r] + bv[r], rv[r], yv[r]);
             }
         }
     }
@@ -386,7 +396,6 @@ __global__ void __launch_bounds__(256, 2) conv_mfma16_kernel(ConvArgs p) {
         const int nl = wn * 64 + j * 16 + r16;
         const int ho = h0 + (nl >> p.TWlog2), wo = w0 + (nl & (p.TW - 1));
         const bool col_ok = ho < p.Ho && wo < p.Wo;
-        const long y_col = y_base + (long)ho * p.y_sh + wo, r_col = r_base + (long)ho * p.r_sh + wo;
         float rv[TM * 4], yv[TM * 4], bv[TM * 4];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -396,8 +405,8 @@ __global__ void __launch_bounds__(256, 2) conv_mfma16_kernel(ConvArgs p) {
                 const bool ok = col_ok && m < p.Cout_g;
                 const int co = g * p.Cout_g + m;
                 bv[i * 4 + r] = (ok && p.bias) ? p.bias[co] : 0.f;
-                rv[i * 4 + r] = (ok && p.res) ? p.res[r_col + (long)co * p.r_sc] : 0.f;
-                yv[i * 4 + r] = (ok && p.accumulate) ? p.y[y_col + (long)co * p.y_sc] : 0.f;
+                rv[i * 4 + r] = (ok && p.res) ? p.res[r_base + out_index(p, co, ho, wo, p.r_sc, p.r_sh)] : 0.f;
+                yv[i * 4 + r] = (ok && p.accumulate) ? p.y[y_base + out_index(p, co, ho, wo, p.y_sc, p.y_sh)] : 0.f;
             }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -406,11 +415,7 @@ __global__ void __launch_bounds__(256, 2) conv_mfma16_kernel(ConvArgs p) {
                 const int m = m_base + i * 16 + q * 4 + r;
                 if (!(col_ok && m < p.Cout_g)) continue;
                 const int co = g * p.Cout_g + m;
-                float v = acc[i][j][r] + bv[i * 4 + r];
-                if (p.res_first) v += rv[i * 4 + r];
-                v = apply_act(v, p.act, p.act_slope);
-                if (!p.res_first) v += rv[i * 4 + r];
-                p.y[y_col + (long)co * p.y_sc] = v * p.out_scale + yv[i * 4 + r];
+                p.y[y_base + out_index(p, co, ho, wo, p.y_sc, p.y_sh)] = combine(p, acc[i][j][r] + bv[i * 4 + r], rv[i * 4 + r], yv[i * 4 + r]);
             }
     }
 }
@@ -537,7 +542,9 @@ __device__ __forceinline__ void ws_produce(const ConvArgs& p, float* xs0, float*
     }
 }
 
-template <int BM, int BN, int WM, int WN, int XR, int KS>
+// GEN: instantiation for shuffle / multiplicative-residual layers (runtime-generic output addressing); kept out of the plain
+// instantiation, whose register allocation it would disturb.
+template <int BM, int BN, int WM, int WN, int XR, int KS, bool GEN>
 __global__ void __launch_bounds__(64 * (WM * WN + 4), (WM * WN == 4 ? 4 : 3)) conv_ws_kernel(ConvArgs p) {
     constexpr int CW = WM * WN, CNT = 64 * CW, PNT = 256;
     constexpr int TM = BM / (32 * WM);
@@ -658,7 +665,7 @@ __global__ void __launch_bounds__(64 * (WM * WN + 4), (WM * WN == 4 ? 4 : 3)) co
                     for (int r = 0; r < 16; ++r) {
                         const int m = m0 + (r & 3) + 8 * (r >> 2);
                         const bool ok = FULL || (col_ok && m < p.Cout_g);
-                        const float t = p.res[ok ? r_col + (long)(g * p.Cout_g + m) * p.r_sc : 0];
+                        const float t = p.res[ok ? (GEN ? r_base + out_index(p, g * p.Cout_g + m, ho, wo, p.r_sc, p.r_sh) : r_col + (long)(g * p.Cout_g + m) * p.r_sc) : 0];
                         rv[r] = ok ? t : 0.f;
                     }
                 }
@@ -667,7 +674,7 @@ __global__ void __launch_bounds__(64 * (WM * WN + 4), (WM * WN == 4 ? 4 : 3)) co
                     for (int r = 0; r < 16; ++r) {
                         const int m = m0 + (r & 3) + 8 * (r >> 2);
                         const bool ok = FULL || (col_ok && m < p.Cout_g);
-                        const float t = p.y[ok ? y_col + (long)(g * p.Cout_g + m) * p.y_sc : 0];
+                        const float t = p.y[ok ? (GEN ? y_base + out_index(p, g * p.Cout_g + m, ho, wo, p.y_sc, p.y_sh) : y_col + (long)(g * p.Cout_g + m) * p.y_sc) : 0];
                         yv[r] = ok ? t : 0.f;
                     }
                 }
@@ -675,11 +682,15 @@ __global__ void __launch_bounds__(64 * (WM * WN + 4), (WM * WN == 4 ? 4 : 3)) co
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + (r & 3) + 8 * (r >> 2);
                     if (!FULL && !(col_ok && m < p.Cout_g)) continue;
-                    float v = acc[i][j][r];
-                    if (p.res_first) v += rv[r];
-                    v = apply_act(v, p.act, p.act_slope);
-                    if (!p.res_first) v += rv[r];
-                    p.y[y_col + (long)(g * p.Cout_g + m) * p.y_sc] = v * p.out_scale + yv[r];
+                    if (GEN) {
+                        p.y[y_base + out_index(p, g * p.Cout_g + m, ho, wo, p.y_sc, p.y_sh)] = combine(p, acc[i][j][r], rv[r], yv[r]);
+                    } else {
+                        float v = acc[i][j][r];
+                        if (p.res_first) v += rv[r];
+                        v = apply_act(v, p.act, p.act_slope);
+                        if (!p.res_first) v += rv[r];
+                        p.y[y_col + (long)(g * p.Cout_g + m) * p.y_sc] = v * p.out_scale + yv[r];
+                    }
                 }
             }
         }
@@ -689,7 +700,7 @@ __global__ void __launch_bounds__(64 * (WM * WN + 4), (WM * WN == 4 ? 4 : 3)) co
 
 // Wave-specialised narrow-M kernel: the consumers of conv_mfma16_kernel (16x16x4 MFMA, every wave covers all BM rows x 64
 // positions of a 256-position tile) fed by ws_produce.  WsGeom pads the weight stage with 4 slack rows (one 16x16x4 k-step).
-template <int BM, int XR, int KS>
+template <int BM, int XR, int KS, bool GEN>
 __global__ void __launch_bounds__(512, 4) conv_ws16_kernel(ConvArgs p) {
     constexpr int CNT = 256;
     constexpr int TM = BM / 16, TN = 4;
@@ -792,7 +803,7 @@ __global__ void __launch_bounds__(512, 4) conv_ws16_kernel(ConvArgs p) {
                 for (int e = 0; e < TM * 4; ++e) {
                     const int m = m_base + (e >> 2) * 16 + q * 4 + (e & 3);
                     const bool ok = FULL || (col_ok && m < p.Cout_g);
-                    const float t = p.res[ok ? r_col + (long)(g * p.Cout_g + m) * p.r_sc : 0];
+                    const float t = p.res[ok ? (GEN ? r_base + out_index(p, g * p.Cout_g + m, ho, wo, p.r_sc, p.r_sh) : r_col + (long)(g * p.Cout_g + m) * p.r_sc) : 0];
                     rv[e] = ok ? t : 0.f;
                 }
             }
@@ -801,7 +812,7 @@ __global__ void __launch_bounds__(512, 4) conv_ws16_kernel(ConvArgs p) {
                 for (int e = 0; e < TM * 4; ++e) {
                     const int m = m_base + (e >> 2) * 16 + q * 4 + (e & 3);
                     const bool ok = FULL || (col_ok && m < p.Cout_g);
-                    const float t = p.y[ok ? y_col + (long)(g * p.Cout_g + m) * p.y_sc : 0];
+                    const float t = p.y[ok ? (GEN ? y_base + out_index(p, g * p.Cout_g + m, ho, wo, p.y_sc, p.y_sh) : y_col + (long)(g * p.Cout_g + m) * p.y_sc) : 0];
                     yv[e] = ok ? t : 0.f;
                 }
             }
@@ -809,11 +820,15 @@ __global__ void __launch_bounds__(512, 4) conv_ws16_kernel(ConvArgs p) {
             for (int e = 0; e < TM * 4; ++e) {
                 const int m = m_base + (e >> 2) * 16 + q * 4 + (e & 3);
                 if (!FULL && !(col_ok && m < p.Cout_g)) continue;
-                float v = acc[e >> 2][j][e & 3];
-                if (p.res_first) v += rv[e];
-                v = apply_act(v, p.act, p.act_slope);
-                if (!p.res_first) v += rv[e];
-                p.y[y_col + (long)(g * p.Cout_g + m) * p.y_sc] = v * p.out_scale + yv[e];
+                if (GEN) {
+                    p.y[y_base + out_index(p, g * p.Cout_g + m, ho, wo, p.y_sc, p.y_sh)] = combine(p, acc[e >> 2][j][e & 3], rv[e], yv[e]);
+                } else {
+                    float v = acc[e >> 2][j][e & 3];
+                    if (p.res_first) v += rv[e];
+                    v = apply_act(v, p.act, p.act_slope);
+                    if (!p.res_first) v += rv[e];
+                    p.y[y_col + (long)(g * p.Cout_g + m) * p.y_sc] = v * p.out_scale + yv[e];
+                }
             }
         }
     };
@@ -997,15 +1012,11 @@ static int launch_conv_ws(ConvArgs& p, hipStream_t stream) {
     if (gx > 2147483647L) return fail(AICG_E_SHAPE, "conv: too many output tiles");
     dim3 grid((unsigned)gx, (unsigned)idiv_up(p.Cout_g, BM), (unsigned)p.groups);
     dim3 block(64 * (WM * WN + 4));
-    if (xr == 8) {
-        auto kern = conv_ws_kernel<BM, BN, WM, WN, 8, KS>;
-        allow_dynamic_lds((const void*)kern, lds);
-        hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
-    } else {
-        auto kern = conv_ws_kernel<BM, BN, WM, WN, 12, KS>;
-        allow_dynamic_lds((const void*)kern, lds);
-        hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
-    }
+    const bool gen = p.shuffle || p.res_mul;
+    auto kern = gen ? (xr == 8 ? conv_ws_kernel<BM, BN, WM, WN, 8, KS, true> : conv_ws_kernel<BM, BN, WM, WN, 12, KS, true>)
+                    : (xr == 8 ? conv_ws_kernel<BM, BN, WM, WN, 8, KS, false> : conv_ws_kernel<BM, BN, WM, WN, 12, KS, false>);
+    allow_dynamic_lds((const void*)kern, lds);
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
     return check_launch("conv_ws_kernel");
 }
 
@@ -1045,15 +1056,11 @@ static int launch_conv16(ConvArgs& p, hipStream_t stream) {
     if (ws && off_ok) {  // wave-specialised form (KSTAGE rows per stage, double-buffered)
         const int xrw = xr <= 8 ? 8 : 12;
         const size_t ldsw = (size_t)(2 * xrw * 256 + 2 * WsGeom<BM, KSTAGE>::WS_ELEMS) * sizeof(float);
-        if (xrw == 8) {
-            auto kern = conv_ws16_kernel<BM, 8, KSTAGE>;
-            allow_dynamic_lds((const void*)kern, ldsw);
-            hipLaunchKernelGGL(kern, grid, dim3(512), ldsw, stream, p);
-        } else {
-            auto kern = conv_ws16_kernel<BM, 12, KSTAGE>;
-            allow_dynamic_lds((const void*)kern, ldsw);
-            hipLaunchKernelGGL(kern, grid, dim3(512), ldsw, stream, p);
-        }
+        const bool gen = p.shuffle || p.res_mul;
+        auto kern = gen ? (xrw == 8 ? conv_ws16_kernel<BM, 8, KSTAGE, true> : conv_ws16_kernel<BM, 12, KSTAGE, true>)
+                        : (xrw == 8 ? conv_ws16_kernel<BM, 8, KSTAGE, false> : conv_ws16_kernel<BM, 12, KSTAGE, false>);
+        allow_dynamic_lds((const void*)kern, ldsw);
+        hipLaunchKernelGGL(kern, grid, dim3(512), ldsw, stream, p);
         return check_launch("conv_ws16_kernel");
     }
     if (xr <= 8) {
@@ -1105,6 +1112,10 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
     p.r_sn = d->r_sn; p.r_sc = d->r_sc; p.r_sh = d->r_sh;
     p.pre_act = d->pre_act; p.pre_slope = d->pre_slope; p.act = d->act; p.act_slope = d->act_slope;
     p.out_scale = d->out_scale; p.accumulate = d->accumulate; p.res_first = d->res_before_act;
+    p.shuffle = d->shuffle; p.res_mul = d->res_mul;
+    if (p.shuffle != 0 && (p.shuffle != 2 || d->Cout % 4 || d->groups != 1))
+        return fail(AICG_E_ARG, "aicg_conv_forward: shuffle must be 0 or 2 (Cout %% 4 == 0, groups == 1)");
+    if (p.res_mul && (!res || d->res_before_act)) return fail(AICG_E_ARG, "aicg_conv_forward: res_mul needs res and res_before_act == 0");
     p.taps = p.KH * p.KW;
     p.Mpad = idiv_up(p.Cout_g, 32) * 32;
     p.Cin_pad = idiv_up(p.Cin_g, 32) * 32;
@@ -1120,7 +1131,7 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
                              ((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0;
         if (pointwise && p.taps == 1 && p.groups == 1 && p.sh == 1 && p.sw == 1 && p.ph == 0 && p.pw == 0 && pad_h_end == 0 &&
             pad_w_end == 0 && (few_in || few_out) && p.Cin_g <= 512 && p.Cout_g <= 512 && p.pre_act == AICG_ACT_NONE &&
-            !p.accumulate && aligned && Ho == p.H && Wo == p.W) {
+            !p.accumulate && aligned && Ho == p.H && Wo == p.W && !p.shuffle && !p.res_mul) {
             const long per_img = (long)Ho * (Wo >> 2);
             dim3 grid((unsigned)ldiv_up(per_img, 256), (unsigned)p.N);
             if (few_in) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_pointwise_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, p);

@@ -88,8 +88,7 @@ class ConvTDFNet:
             x = ops.conv(x, down, act=ops.ACT_RELU)
         x = self.mid(x)
         for i, (up, dense) in enumerate(zip(self.us, self.us_dense)):
-            x = ops.conv_transpose(x, up, act=ops.ACT_RELU)
-            x = ops.mul(x, skips[-i - 1], out=x)
+            x = ops.conv_transpose(x, up, act=ops.ACT_RELU, mul=skips[-i - 1])  # x = relu(bn(convT(x))) * skip, one kernel
             x = dense(x)
         return ops.conv(x, self.final)
 

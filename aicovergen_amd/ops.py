@@ -119,7 +119,8 @@ class ConvDesc(ctypes.Structure):
                [(n, ctypes.c_int64) for n in ("x_sn", "x_sc", "x_sh", "y_sn", "y_sc", "y_sh", "r_sn", "r_sc", "r_sh")] + \
                [("pre_act", ctypes.c_int32), ("pre_slope", ctypes.c_float), ("act", ctypes.c_int32),
                 ("act_slope", ctypes.c_float), ("out_scale", ctypes.c_float), ("accumulate", ctypes.c_int32),
-                ("res_before_act", ctypes.c_int32), ("pad_h_end", ctypes.c_int32), ("pad_w_end", ctypes.c_int32)]
+                ("res_before_act", ctypes.c_int32), ("pad_h_end", ctypes.c_int32), ("pad_w_end", ctypes.c_int32),
+                ("shuffle", ctypes.c_int32), ("res_mul", ctypes.c_int32)]
 
 
 def conv_bkc(taps):
@@ -201,7 +202,7 @@ conv_profile = None
 
 
 def conv(x, pc, res=None, out=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NONE, act_slope=0.0, out_scale=1.0,
-         accumulate=False, bias=None, res_before_act=False, out_len=None):
+         accumulate=False, bias=None, res_before_act=False, out_len=None, shuffle=0, res_mul=False):
     """y = [y +] out_scale * (act(conv(pre_act(x)) + bias) + res).  x: (N,C,T) or (N,C,H,W), last dim contiguous;
     views with arbitrary batch/channel/row strides are accepted for x, res and out."""
     is1d = x.dim() == 3
@@ -213,11 +214,14 @@ def conv(x, pc, res=None, out=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NON
     if out_len is not None:  # compute only the first out_len columns (e.g. SamePad of an even kernel)
         assert out_len <= wo
         wo = out_len
+    # shuffle = 2: this is the GEMM of a kernel = stride = 2 ConvTranspose2d and the epilogue scatters row m of position
+    # (ho, wo) to out[m >> 2][2 ho + ((m >> 1) & 1)][2 wo + (m & 1)] (see conv_transpose)
+    oshape = (n, pc.cout // 4, 2 * ho, 2 * wo) if shuffle else (n, pc.cout, ho, wo)
     if out is None:
-        out = torch.empty((n, pc.cout, wo) if is1d else (n, pc.cout, ho, wo), dtype=torch.float32, device=x.device)
+        out = torch.empty((n, pc.cout, wo) if is1d else oshape, dtype=torch.float32, device=x.device)
         assert not accumulate
     o4 = _as4d(out)
-    assert o4.shape == (n, pc.cout, ho, wo), (o4.shape, (n, pc.cout, ho, wo))
+    assert o4.shape == oshape, (o4.shape, oshape)
     assert o4.stride(3) == 1 or wo == 1
     r4 = None
     if res is not None:
@@ -240,6 +244,7 @@ def conv(x, pc, res=None, out=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NON
     d.out_scale, d.accumulate = out_scale, 1 if accumulate else 0
     d.res_before_act = 1 if res_before_act else 0
     d.pad_h_end, d.pad_w_end = (-1, -1) if pc.padding_end is None else pc.padding_end
+    d.shuffle, d.res_mul = int(shuffle), 1 if res_mul else 0
     prof = conv_profile
     if prof is not None and x.is_cuda:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -274,6 +279,8 @@ class PackedConvTranspose:
         gemm_w = weight.detach().permute(1, 2, 3, 0).reshape(self.cout * self.kh * self.kw, self.cin)
         self.gemm = PackedConv(gemm_w.contiguous(), None, device=device)
         self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
+        # per-GEMM-row bias for the fused kernel = stride = 2 form (row = co * 4 + tap)
+        self.bias4 = None if self.bias is None else self.bias.repeat_interleave(self.kh * self.kw).contiguous()
 
     def out_hw(self, h, w):
         ho = (h - 1) * self.stride[0] - 2 * self.padding[0] + self.kh + self.output_padding[0]
@@ -281,11 +288,17 @@ class PackedConvTranspose:
         return ho, wo
 
 
-def conv_transpose(x, pt, out=None, add=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NONE, act_slope=0.0):
-    """y = act(conv_transpose(pre_act(x)) + bias) + add."""
+def conv_transpose(x, pt, out=None, add=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NONE, act_slope=0.0, mul=None):
+    """y = act(conv_transpose(pre_act(x)) + bias) + add   (or ... * mul: the MDX U-Net's multiplicative skip)."""
     is1d = x.dim() == 3
     x4 = _as4d(x)
     n, c, h, w = x4.shape
+    assert add is None or mul is None
+    if (not is1d and (pt.kh, pt.kw) == (2, 2) and pt.stride == (2, 2) and pt.padding == (0, 0)
+            and pt.output_padding == (0, 0)):
+        # non-overlapping taps: every output element is one GEMM element -> scatter + bias + act + skip in the GEMM epilogue
+        return conv(x4, pt.gemm, res=add if mul is None else mul, out=out, pre_act=pre_act, pre_slope=pre_slope, act=act,
+                    act_slope=act_slope, bias=pt.bias4, shuffle=2, res_mul=mul is not None)
     cols = conv(x4, pt.gemm, pre_act=pre_act, pre_slope=pre_slope)  # (N, Cout*KH*KW, H, W)
     ho, wo = pt.out_hw(h, w)
     if out is None:
@@ -300,6 +313,8 @@ def conv_transpose(x, pt, out=None, add=None, pre_act=ACT_NONE, pre_slope=0.0, a
     _lib.call("aicg_col2im", _ptr(cols), _ptr(pt.bias), _ptr(a4), _ptr(o4), n, pt.cout, h, w, ho, wo, pt.kh, pt.kw,
               pt.stride[0], pt.stride[1], pt.padding[0], pt.padding[1], act, act_slope,
               o4.stride(0), o4.stride(1), o4.stride(2), asn, asc, ash, _stream(x))
+    if mul is not None:
+        globals()["mul"](out, mul, out=out)
     return out
 
 

@@ -104,6 +104,11 @@ typedef struct aicg_conv_desc {
     int32_t res_before_act; /* nonzero: y = out_scale * act(acc + bias + res)  (e.g. emb_phone + emb_pitch -> lrelu) */
     int32_t pad_h_end, pad_w_end; /* zero padding after the last row / column; -1 = same as pad_h / pad_w
                                      (torchcrepe pads (31, 32) around its k=64 convs) */
+    int32_t shuffle;              /* 0, or 2: the layer is the 1x1 GEMM of a kernel = stride = 2 ConvTranspose2d
+                                     (mdx U-Net `us.*`): GEMM row m at position (ho, wo) is stored to
+                                     y[n][m >> 2][2 ho + ((m >> 1) & 1)][2 wo + (m & 1)]; y (and res) strides describe that
+                                     (N, Cout/4, 2 Ho, 2 Wo) tensor, bias has Cout entries */
+    int32_t res_mul;              /* nonzero: y = out_scale * (act(acc + bias) * res) -- multiplicative U-Net skip */
 } aicg_conv_desc;
 
 int aicg_conv_bkc(int taps);

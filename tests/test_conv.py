@@ -130,3 +130,17 @@ def test_pointwise_streaming_form(dev, n, ci, co, h, w):
     ops.conv(big[:, 2:2 + ci], pc, out=outbig[:, 8:8 + co])
     assert rel_rms(outbig[:, 8:8 + co], F.conv2d(big.cpu()[:, 2:2 + ci], wt, b)) < 1e-6
     assert float(outbig[:, :8].abs().sum()) == 0 and float(outbig[:, 8 + co:].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("n,ci,co,h,w", [(2, 24, 12, 5, 9), (1, 96, 48, 16, 96), (1, 20, 12, 130, 520), (1, 64, 32, 64, 520)])
+def test_conv_transpose_k2s2_fused_epilogue(dev, n, ci, co, h, w):
+    """kernel = stride = 2 ConvTranspose2d (MDX-Net `us.*`): the GEMM epilogue scatters to the 2x upsampled grid and applies
+    bias + ReLU + the multiplicative U-Net skip (or an additive one); small, 32x32-tile and 16x16-tile dispatches."""
+    torch.manual_seed(co)
+    x, wt, b = torch.randn(n, ci, h, w), torch.randn(ci, co, 2, 2) * 0.2, torch.randn(co)
+    skip = torch.randn(n, co, 2 * h, 2 * w)
+    pt = ops.PackedConvTranspose(wt, b, stride=2, device=dev.device)
+    ref = F.conv_transpose2d(x, wt, b, stride=2)
+    assert rel_rms(ops.conv_transpose(dev.t(x), pt, act=ops.ACT_RELU, mul=dev.t(skip)), F.relu(ref) * skip) < 1e-5
+    assert rel_rms(ops.conv_transpose(dev.t(x), pt, add=dev.t(skip)), ref + skip) < 1e-5
+    assert rel_rms(ops.conv_transpose(dev.t(x), pt), ref) < 1e-5
