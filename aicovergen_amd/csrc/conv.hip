@@ -611,15 +611,21 @@ __global__ void __launch_bounds__(64 * (WM * WN + 4), (WM * WN == 4 ? 4 : 3)) co
             const int nt = imin(p.TT, p.taps - tap0);
             const int nsteps = nt * (p.BKC >> 1);
             float a0[TM], b0[TN], a1[TM], b1[TN];
-            int kh = tap0 / p.KW, kw = tap0 - kh * p.KW, kk = 0;
+            // patch offset of the (tap, channel pair) being fetched, advanced incrementally: + 2 channels per k-step, then to
+            // the next column tap, then to the next kernel row
+            const int kh0 = tap0 / p.KW;
+            int kw = tap0 - kh0 * p.KW, kk = 0;
+            int xoff = kh0 * p.dh * p.TWp + kw * p.dw;
+            const int step_k = 2 * p.CHS, next_tap = p.dw - p.BKC * p.CHS, next_row = p.dh * p.TWp - p.KW * p.dw;
             auto fetch = [&](float (&a)[TM], float (&b)[TN], int s) {
-                const float* xt = xs + kh * p.dh * p.TWp + kw * p.dw + kk * p.CHS;
+                const float* xt = xs + xoff;
 #pragma unroll
                 for (int i = 0; i < TM; ++i) a[i] = wt[s * 2 * BM + i * 32];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) b[j] = xt[boff[j]];
+                xoff += step_k;
                 kk += 2;
-                if (kk == p.BKC) { kk = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
+                if (kk == p.BKC) { kk = 0; xoff += next_tap; if (++kw == p.KW) { kw = 0; xoff += next_row; } }
             };
             auto mma = [&](float (&a)[TM], float (&b)[TN]) {
 #pragma unroll
@@ -755,15 +761,19 @@ __global__ void __launch_bounds__(512, 4) conv_ws16_kernel(ConvArgs p) {
             const int nt = imin(p.TT, p.taps - tap0);
             const int nsteps = nt * (p.BKC >> 2);  // k-steps of 4 rows
             float a0[TM], b0[TN], a1[TM], b1[TN];
-            int kh = tap0 / p.KW, kw = tap0 - kh * p.KW, kk = 0;
+            const int kh0 = tap0 / p.KW;
+            int kw = tap0 - kh0 * p.KW, kk = 0;
+            int xoff = kh0 * p.dh * p.TWp + kw * p.dw;
+            const int step_k = 4 * p.CHS, next_tap = p.dw - p.BKC * p.CHS, next_row = p.dh * p.TWp - p.KW * p.dw;
             auto fetch = [&](float (&a)[TM], float (&b)[TN], int s) {
-                const float* xt = xs + kh * p.dh * p.TWp + kw * p.dw + kk * p.CHS;
+                const float* xt = xs + xoff;
 #pragma unroll
                 for (int i = 0; i < TM; ++i) a[i] = wt[s * 4 * BM + i * 16];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) b[j] = xt[boff[j]];
+                xoff += step_k;
                 kk += 4;
-                if (kk == p.BKC) { kk = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
+                if (kk == p.BKC) { kk = 0; xoff += next_tap; if (++kw == p.KW) { kw = 0; xoff += next_row; } }
             };
             auto mma = [&](float (&a)[TM], float (&b)[TN]) {
 #pragma unroll
