@@ -165,3 +165,27 @@ def test_attention_key_split_matches_single_pass(dev, win):
     for s in (2, 7):
         many = ops.attention(dev.t(q), dev.t(k), dev.t(v), H, relk=relk, relv_emb=ev, window=win, n_splits=s)
         assert rel_rms(many, one.cpu()) < 2e-6
+
+
+@pytest.mark.parametrize("R,K,O", [(300, 64, 40), (515, 100, 130), (128, 36, 256)])
+def test_linear_last_nt_gemm(dev, R, K, O):
+    """TDF linear over the last axis (NT GEMM, wave-specialised): ragged rows / K slab / output tile, with the fused
+    bias + per-channel affine (eval BatchNorm2d) + ReLU + residual epilogue."""
+    torch.manual_seed(R + K)
+    if dev.big:
+        R = R * 40 + 3
+    n_ch, rows_per_ch = 5, 7
+    x = torch.randn(R, K)
+    w, b = torch.randn(O, K) * 0.2, torch.randn(O)
+    sc, sh = torch.rand(n_ch) + 0.5, torch.randn(n_ch)
+    res = torch.randn(R, O)
+    ch = (torch.arange(R) // rows_per_ch) % n_ch
+    ref = torch.relu((x @ w.t() + b) * sc[ch, None] + sh[ch, None]) + res
+    out = torch.empty(R, O)
+    from aicovergen_amd import _lib
+    o = dev.t(out)
+    xd, wd, bd, scd, shd, rd = (dev.t(t) for t in (x, w, b, sc, sh, res))
+    st = torch.cuda.current_stream().cuda_stream if dev.kind == "hip" else 0
+    _lib.call("aicg_gemm_nt", xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), scd.data_ptr(), shd.data_ptr(), rd.data_ptr(),
+              o.data_ptr(), R, K, O, K, K, O, O, rows_per_ch, n_ch, ops.ACT_RELU, st)
+    assert rel_rms(o, ref) < 1e-5
