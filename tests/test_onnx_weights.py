@@ -79,3 +79,34 @@ def test_not_a_unet_is_a_clear_error(tmp_path):
     p.write_bytes(b"\x08\x07")  # ModelProto with ir_version only
     with pytest.raises(ValueError, match="GraphProto"):
         onnx_weights.load_onnx_state_dict(str(p))
+
+
+@pytest.mark.gpu
+def test_run_mdx_end_to_end_from_onnx_and_wav_files(tmp_path):
+    """The reference's own entry point, file in -> files out (src/mdx.py:238-287): model hash -> model_data entry, `.onnx`
+    weights, WAV input, denoise on; main and inverted stems against the oracle's run_mdx arithmetic after PCM-16 rounding."""
+    import conftest
+    conftest._bind("hip")
+    from aicovergen_amd import audio_io
+    from aicovergen_amd.mdx import MDX, run_mdx
+    from synthetic.inputs import song_like
+    cfg = dict(CFG, n_fft=2048, dim_t=16)  # hop is 1024 in MDXModel: chunk = 15 360 samples
+    wave = song_like(1.5, 44100, seed=9).astype(np.float32) * 0.6
+    wav = tmp_path / "song.wav"
+    audio_io.write_wav_pcm16(str(wav), wave.T, 44100)
+    params = {MDX.get_hash(FIXTURE): {"mdx_dim_f_set": cfg["dim_f"], "mdx_dim_t_set": 4, "mdx_n_fft_scale_set": 2048,
+                                      "primary_stem": "Vocals", "compensate": 1.021}}
+    main, inv = run_mdx(params, str(tmp_path), FIXTURE, str(wav), denoise=True, keep_orig=True)
+    assert os.path.basename(main) == "song_Vocals.wav" and os.path.basename(inv) == "song_Instrumental.wav"
+    got_main, sr = audio_io.load_wav(main, 44100, mono=False)
+    got_inv, _ = audio_io.load_wav(inv, 44100, mono=False)
+    assert sr == 44100
+    src, _ = audio_io.load_wav(str(wav), 44100, mono=False)   # what run_mdx actually read (PCM-16 rounded)
+    ref_main, ref_inv = mdxnet.run_mdx_arrays(weights.mdx_state_dict(CFG, 7), cfg, src.astype(np.float64), True, 1.021, 2)
+    lsb = 1.0 / 32768
+    assert got_main.shape == ref_main.shape
+    # the seeded random network is not gain-normalised (|out| up to ~3, the WAV writer clips like soundfile does):
+    # tolerance = PCM rounding + 1e-4 of the unclipped signal range
+    tol = 2 * lsb + 1e-4 * max(1.0, float(np.abs(ref_main).max()), float(np.abs(ref_inv).max()))
+    assert np.abs(got_main - np.clip(ref_main, -1, 1)).max() < tol
+    assert np.abs(got_inv - np.clip(ref_inv, -1, 1)).max() < tol
