@@ -488,6 +488,8 @@ def gru_bidir(gi, whh_t, bhh, hidden, two_workgroups=None):
         # the kernel's exchange-timeout flag is read back lazily (gru_check_pending): an .item() here would park the host
         # until the recurrence ends, which is exactly the time pipeline() wants to spend queueing HuBERT work
         _gru_pending.append(scratch[32 * hidden: 32 * hidden + 4].view(torch.int32))
+        if len(_gru_pending) > 16:  # a caller that never checks: bound the backlog (this one synchronises)
+            gru_check_pending()
         return out
     _lib.call("aicg_gru_bidir", _ptr(gi), _ptr(whh_t), _ptr(bhh), _ptr(out), hidden, t, _stream(gi))
     return out
