@@ -144,3 +144,35 @@ def test_conv_transpose_k2s2_fused_epilogue(dev, n, ci, co, h, w):
     assert rel_rms(ops.conv_transpose(dev.t(x), pt, act=ops.ACT_RELU, mul=dev.t(skip)), F.relu(ref) * skip) < 1e-5
     assert rel_rms(ops.conv_transpose(dev.t(x), pt, add=dev.t(skip)), ref + skip) < 1e-5
     assert rel_rms(ops.conv_transpose(dev.t(x), pt), ref) < 1e-5
+
+
+def test_single_role_fallback_kernels_in_a_subprocess():
+    """conv_mfma_kernel / conv_mfma16_kernel are the fallbacks when a layer does not fit the wave-specialised kernels' LDS
+    budget; the dispatch switches are read once per process, so they are exercised in a child process on the emulator."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, torch, torch.nn.functional as F
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import conftest
+conftest._bind("emu")
+from aicovergen_amd import ops
+torch.manual_seed(0)
+def rel(a, b): return float(((a - b).pow(2).sum() / b.pow(2).sum()).sqrt())
+for (n, ci, co, h, w, k) in [(1, 20, 40, 70, 1000, 3), (1, 16, 16, 1, 70000, 3), (2, 33, 64, 9, 130, 3), (1, 4, 48, 8, 64, 1)]:
+    x, wt, b, r = torch.randn(n, ci, h, w), torch.randn(co, ci, k if h > 1 else 1, k) * 0.1, torch.randn(co), torch.randn(n, co, h, w)
+    pc = ops.PackedConv(wt, b, padding=(k // 2 if h > 1 else 0, k // 2))
+    y = ops.conv(x, pc, act=ops.ACT_RELU, res=r)
+    e = rel(y, F.relu(F.conv2d(x, wt, b, padding=(k // 2 if h > 1 else 0, k // 2))) + r)
+    assert e < 1e-5, (n, ci, co, h, w, k, e)
+wt = torch.randn(24, 12, 2, 2) * 0.2
+pt = ops.PackedConvTranspose(wt, torch.randn(12), stride=2)
+x, skip = torch.randn(2, 24, 5, 9), torch.randn(2, 12, 10, 18)
+assert rel(ops.conv_transpose(x, pt, act=ops.ACT_RELU, mul=skip), F.relu(F.conv_transpose2d(x, wt, pt.bias, stride=2)) * skip) < 1e-5
+print("fallback kernels ok")
+''' % (root, os.path.join(root, "tests"))
+    env = dict(os.environ, AICG_CONV_WS="0", AICG_CONV_POINTWISE="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "fallback kernels ok" in out.stdout, out.stdout + out.stderr
