@@ -275,7 +275,11 @@ class VC(object):
         f0_wait = 0.0
         if overlap:
             main = torch.cuda.current_stream(self.device)
-            side = torch.cuda.Stream(device=self.device)
+            # one side stream per VC object: the caching allocator keeps a block pool per stream, a fresh stream per call
+            # would strand RMVPE's working set (a few GB for a 4-minute track) in up to 32 pools
+            side = getattr(self, "_f0_stream", None)
+            if side is None:
+                side = self._f0_stream = torch.cuda.Stream(device=self.device)
             # one upload of the padded track: a pageable host->device copy on the default stream waits for the whole device,
             # side stream included, so the chunk loop below must not issue any
             pad_dev = torch.from_numpy(np.ascontiguousarray(audio_pad)).to(self.device).float()
