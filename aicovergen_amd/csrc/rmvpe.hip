@@ -3,6 +3,8 @@
 // (src/vc_infer_pipeline.py:361-368).  The convolutions of the DeepUnet run through conv.hip.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace aicg {
 
 // |re + i im| elementwise (rmvpe.py:314: magnitude = sqrt(real^2 + imag^2))
@@ -125,11 +127,11 @@ __global__ void __launch_bounds__(3 * HD / 2) gru_kernel(const float* __restrict
 // dot product plus one exchange of HD/2 new h values with the partner.  The exchange follows the tagged-granule
 // recipe of the CDNA guide (G16 / R2): one 8-byte {tag = step+1, value} agent-scope store per unit, polled with
 // relaxed agent-scope loads; two parity slots because the partner may run one step ahead.  The four workgroups of a
-// launch are co-resident by construction (grid = 4 on a 256-CU device); spins are bounded and report through `err`.
+// launch are co-resident by construction (4 working blocks on a 256-CU device); spins are bounded and report through `err`.
 template <int HD, int KR>
 __global__ void __launch_bounds__(3 * HD / 2) gru2_kernel(const float* __restrict__ gi, const float* __restrict__ whh_t,
                                                           const float* __restrict__ bhh, float* __restrict__ out, long T,
-                                                          unsigned long long* xbuf, int* err) {
+                                                          unsigned long long* xbuf, int* err, int force_agent) {
     constexpr int HH = HD / 2;      // units per workgroup
     constexpr int NT = 3 * HH;      // threads = gate rows per workgroup
     constexpr int KL = HD - KR;
@@ -139,8 +141,27 @@ __global__ void __launch_bounds__(3 * HD / 2) gru2_kernel(const float* __restric
     float* h = smem;                // HD
     float* gh = smem + HD;          // NT
     float* wl = smem + HD + NT;     // KL x NT
-    const int dir = blockIdx.x >> 1, part = blockIdx.x & 1;
+    // 16 blocks are launched and 4 work: blocks b and b + 8 are observed to land on the same XCD (b % 8), so the two halves of
+    // a direction can hand h over through that XCD's L2.  Placement is not a contract: the pair compares HW_REG_XCC_ID at
+    // start and only then publishes with plain stores (which keep the line in the local L2; sc1 / atomic stores drop it and
+    // the partner reads at the cross-XCD rate -- MI355X_MICROARCH "stores of each flavour"); otherwise agent-scope stores.
+    if ((blockIdx.x & 7) > 1) return;
+    const int dir = blockIdx.x & 7, part = blockIdx.x >> 3;
     const int t_ = threadIdx.x;
+    __shared__ int same_xcd_s;
+    if (t_ == 0) {
+        int* xcc = err + 4;  // 4 ints inside the zeroed 64-byte tail of the scratch buffer
+        const int me = (int)(__builtin_amdgcn_s_getreg(6164) & 0xF) + 1;  // HW_REG_XCC_ID (id 20), bits [3:0]
+        __hip_atomic_store(xcc + dir * 2 + part, me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int other = 0, spins = 0;
+        while ((other = __hip_atomic_load(xcc + dir * 2 + (1 - part), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+            if (++spins > (1 << 22)) { *err = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        same_xcd_s = (other == me) && !force_agent;
+    }
+    __syncthreads();
+    const bool same_xcd = same_xcd_s != 0;
     const int gate = t_ / HH, u = t_ - gate * HH;
     const int row = gate * HD + part * HH + u;          // row of W_hh (3*HD x HD), [r ; z ; n]
     const float* W = whh_t + (long)dir * HD * 3 * HD;   // k-major: W[k * 3*HD + row]
@@ -203,7 +224,8 @@ __global__ void __launch_bounds__(3 * HD / 2) gru2_kernel(const float* __restric
             h[my_unit] = hn;
             od[(long)my_unit * T + t] = hn;
             const unsigned long long gran = ((unsigned long long)(unsigned)(s + 1) << 32) | (unsigned)__float_as_int(hn);
-            __hip_atomic_store(mine + par * HH + u, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (same_xcd) mine[par * HH + u] = gran;  // one 8-byte store: the poller's sc1 load finds it in the shared L2
+            else __hip_atomic_store(mine + par * HH + u, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (t_ >= PW && t_ < PW + HH) {
             // a different WAVE than the publishers (a wave that polled first while its own lanes still had to publish
             // would deadlock against the partner doing the same): fetch the partner's new h values for this step
@@ -351,17 +373,18 @@ extern "C" int aicg_gru_bidir_2wg(const float* gi, const float* whh_t, const flo
     (void)hipMemsetAsync(xchg_scratch, 0, xbytes + 64, (hipStream_t)stream);
     unsigned long long* xb = (unsigned long long*)xchg_scratch;
     int* err = (int*)((char*)xchg_scratch + xbytes);
+    static const int force_agent = getenv("AICG_GRU_AGENT_STORES") ? atoi(getenv("AICG_GRU_AGENT_STORES")) : 0;  // A/B switch
     if (hidden == 256) {
         constexpr int KR = 208;
         const size_t lds = (size_t)(256 + 384 + (256 - KR) * 384) * sizeof(float);
         auto kern = gru2_kernel<256, KR>;
         allow_dynamic_lds((const void*)kern, lds);
-        hipLaunchKernelGGL(kern, dim3(4), dim3(384), lds, (hipStream_t)stream, gi, whh_t, bhh, out, (long)T, xb, err);
+        hipLaunchKernelGGL(kern, dim3(16), dim3(384), lds, (hipStream_t)stream, gi, whh_t, bhh, out, (long)T, xb, err, force_agent);
     } else if (hidden == 64) {
         constexpr int KR = 48;
         const size_t lds = (size_t)(64 + 96 + (64 - KR) * 96) * sizeof(float);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(gru2_kernel<64, KR>), dim3(4), dim3(96), lds, (hipStream_t)stream, gi, whh_t, bhh, out,
-                           (long)T, xb, err);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gru2_kernel<64, KR>), dim3(16), dim3(96), lds, (hipStream_t)stream, gi, whh_t, bhh, out,
+                           (long)T, xb, err, force_agent);
     } else {
         return fail(AICG_E_SHAPE, "aicg_gru_bidir_2wg: hidden size %d not instantiated (256, 64)", hidden);
     }

@@ -196,6 +196,7 @@ inline emu_f32x4 emu_mfma_f32_16x16x4f32(float a, float b, emu_f32x4 c, int, int
 #define __builtin_amdgcn_mfma_f32_32x32x2f32 emu_mfma_f32_32x32x2f32
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 emu_mfma_f32_16x16x4f32
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_s_getreg(x) 0u
 #define __builtin_amdgcn_s_sleep(x) ::emu::yield_any()
 // agent-scope atomics on global memory: workgroups run on different OS threads in the emulator
 #define __HIP_MEMORY_SCOPE_AGENT 3
