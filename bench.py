@@ -190,6 +190,7 @@ def main():
                        "wall_split_seconds_per_step": split},
             "roofline": {"bound": "mfma", "achieved": conv["tflops"], "peak": 157.3, "unit": "TFLOP/s",
                          "frac": conv["tflops"] / 157.3, "traffic": pmc_traffic_per_launch(),
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/r01_summary.json)",
                          "kernel": "conv_ws_kernel family (fp32 MFMA implicit GEMM: conv_ws / conv_ws16 / conv_mfma / conv_mfma16)",
                          "launches_per_step": conv["launches"] / args.steps,
                          "algorithmic_tflop_per_step": conv["flops"] / args.steps / 1e12,
