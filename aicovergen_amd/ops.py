@@ -228,6 +228,8 @@ def conv(x, pc, res=None, out=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NON
         r4 = _as4d(res)
         assert r4.shape == o4.shape and (r4.stride(3) == 1 or wo == 1)
     b = pc.bias if bias is None else bias
+    if o4.numel() == 0:  # empty batch / no output positions: nothing to launch (empty tensors have no storage to point at)
+        return out
     _check(x, out, res, pc.w, b)
     d = ConvDesc()
     d.N, d.Cin, d.H, d.W, d.Cout, d.Ho, d.Wo = n, c, h, w, pc.cout, ho, wo
