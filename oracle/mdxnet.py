@@ -2,9 +2,10 @@
 (src/mdx.py): MDXModel.stft / istft, MDX.segment / pad_wave / _process_wave / process_wave and run_mdx's
 peak-normalise / denoise / invert arithmetic, plus the TFC-TDF U-Net the ONNX file contains.
 
-The framing / STFT code below is pinned against the reference's own mdx.py (imported with stubs for the missing
-third-party modules) in tests/golden/make_golden.py -> tests/golden/mdx_*.npz.  The U-Net itself lives only in the
-downloaded .onnx files (not available offline): restated from the published kuielab "ConvTDFNet"; PARITY UNPINNED.
+The framing / STFT / denoise / inversion code below is pinned against the reference's own src/mdx.py, run in the build
+container with only onnxruntime / librosa / soundfile stubbed (tests/golden/make_mdx_golden.py -> tests/golden/
+mdx_ref_tiny.npz, replayed bit-exactly by tests/test_oracle_golden.py).  The U-Net itself lives only in the downloaded
+.onnx files (not available offline): restated from the published kuielab "ConvTDFNet"; PARITY UNPINNED for the network.
 """
 import numpy as np
 import torch

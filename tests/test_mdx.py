@@ -115,3 +115,25 @@ def test_voc_ft_sized_window_matches_oracle():
         ref = mdxnet.istft(mdxnet.unet(sd, cfg, mdxnet.stft(x, cfg["n_fft"], 1024, cfg["dim_f"])), cfg["n_fft"], 1024)
         got = model.istft_tf(sess.net.forward_tf(model.stft_tf(x.cuda())))
     assert rel_rms(got, ref) < 1e-4
+
+
+def test_separation_matches_reference_golden(dev):
+    """The whole separator (real hop 1024, n_fft 2048, denoise on and off) on the HIP kernels against arrays written by the
+    REFERENCE's run_mdx (tests/golden/mdx_ref_tiny.npz; the network inside the reference run was the restated U-Net with the
+    same seeded parameters)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "mdx_ref_tiny.npz"))
+    cfg = dict(weights.MDX_TINY, n_fft=2048, dim_t=16)
+    _, model, sess = _session(dev, cfg, hop=1024, seed=7)
+    wave = g["wave"].astype(np.float32)
+    peak = max(np.max(wave), abs(np.min(wave)))
+    norm = wave / peak
+    scale = max(1.0, float(np.abs(g["main_plain"]).max()))
+    for denoise, tag in ((True, "dn"), (False, "plain")):
+        got = run_mdx_arrays(sess, norm.copy(), denoise, 2) * peak
+        assert got.shape == g["main_" + tag].shape
+        assert np.abs(got - g["main_" + tag]).max() < 1e-4 * scale
+        inv = (-got * 1.021) + norm                      # mdx.py:280 adds the normalised wave
+        assert np.abs(inv - g["inv_" + tag]).max() < 1e-4 * scale
+    mix, pad, trim = sess.pad_wave(g["pad_in"])
+    assert [pad, trim] == g["pad_trim"].tolist() and np.array_equal(mix.cpu().numpy(), g["pad_windows"])

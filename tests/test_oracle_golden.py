@@ -69,3 +69,46 @@ def test_oracle_decode_matches_reference_loop():
         s9, m9 = sp[i, c - 4:c + 5], cm[c - 4:c + 5]
         want.append(np.sum(s9 * m9) / np.sum(s9) if sp[i].max() > 0.05 else 0.0)
     assert np.allclose(orm.to_local_average_cents(sal, 0.05), np.array(want), rtol=1e-12)
+
+
+# ---- MDX-Net separator path: the oracle's restatement of src/mdx.py against outputs of the reference module itself -------
+# (tests/golden/make_mdx_golden.py ran the reference's MDXModel / MDX / run_mdx with only onnxruntime, librosa and soundfile
+# stubbed; the stub network is the restated U-Net, so everything AROUND the network is pinned here)
+def _mdx_gold():
+    import numpy as np
+    g = np.load(os.path.join(GOLD, "mdx_ref_tiny.npz"))
+    cfg = dict(weights.MDX_TINY, n_fft=2048, dim_t=16)
+    return g, cfg, weights.mdx_state_dict(weights.MDX_TINY, 7)
+
+
+def test_oracle_mdx_stft_istft_match_reference():
+    from oracle import mdxnet
+    g, cfg, _ = _mdx_gold()
+    spec = mdxnet.stft(torch.from_numpy(g["stft_in"]), cfg["n_fft"], 1024, cfg["dim_f"])
+    assert torch.equal(spec, torch.from_numpy(g["stft_out"]))                      # same torch ops on the same CPU
+    assert torch.equal(mdxnet.istft(spec, cfg["n_fft"], 1024), torch.from_numpy(g["istft_out"]))
+
+
+def test_oracle_mdx_window_bookkeeping_matches_reference():
+    import numpy as np
+    from oracle import mdxnet
+    g, cfg, _ = _mdx_gold()
+    mix, pad, trim = mdxnet.pad_wave(g["pad_in"], cfg["n_fft"], 1024 * (cfg["dim_t"] - 1))
+    assert [pad, trim] == g["pad_trim"].tolist()
+    assert np.array_equal(mix.numpy(), g["pad_windows"])
+    segs = mdxnet.segment(g["pad_in"], False, 15000)
+    assert [s.shape[-1] for s in segs] == g["seg_lens"].tolist()
+    assert mdxnet.segment(segs, True, 15000).shape == g["seg_joined"].shape       # the reference's own short-wave edge case
+
+
+def test_oracle_run_mdx_matches_reference():
+    import numpy as np
+    from oracle import mdxnet
+    g, cfg, sd = _mdx_gold()
+    wave = g["wave"].astype(np.float32)
+    norm = wave / max(np.max(wave), abs(np.min(wave)))
+    assert np.array_equal(mdxnet.process_wave(sd, cfg, norm, 2).astype(np.float32), g["process_wave"])
+    for denoise, tag in ((True, "dn"), (False, "plain")):
+        main, inv = mdxnet.run_mdx_arrays(sd, cfg, wave, denoise, 1.021, 2)
+        assert np.abs(main - g["main_" + tag]).max() < 1e-6
+        assert np.abs(inv - g["inv_" + tag]).max() < 1e-6
