@@ -141,12 +141,13 @@ __global__ void __launch_bounds__(3 * HD / 2) gru2_kernel(const float* __restric
     float* h = smem;                // HD
     float* gh = smem + HD;          // NT
     float* wl = smem + HD + NT;     // KL x NT
-    // 16 blocks are launched and 4 work: blocks b and b + 8 are observed to land on the same XCD (b % 8), so the two halves of
-    // a direction can hand h over through that XCD's L2.  Placement is not a contract: the pair compares HW_REG_XCC_ID at
+    // 32 blocks are launched and 4 work (0, 8, 16, 24): blocks b and b + 8 are observed to land on the same XCD (b % 8), so the
+    // two halves of a direction can hand h over through that XCD's L2.  (Partners are adjacent in dispatch order among the
+    // working blocks, so two host threads suffice to run the pair concurrently in the CPU emulator.)  Placement is not a contract: the pair compares HW_REG_XCC_ID at
     // start and only then publishes with plain stores (which keep the line in the local L2; sc1 / atomic stores drop it and
     // the partner reads at the cross-XCD rate -- MI355X_MICROARCH "stores of each flavour"); otherwise agent-scope stores.
-    if ((blockIdx.x & 7) > 1) return;
-    const int dir = blockIdx.x & 7, part = blockIdx.x >> 3;
+    if (blockIdx.x & 7) return;
+    const int dir = blockIdx.x >> 4, part = (blockIdx.x >> 3) & 1;
     const int t_ = threadIdx.x;
     __shared__ int same_xcd_s;
     if (t_ == 0) {
@@ -379,11 +380,11 @@ extern "C" int aicg_gru_bidir_2wg(const float* gi, const float* whh_t, const flo
         const size_t lds = (size_t)(256 + 384 + (256 - KR) * 384) * sizeof(float);
         auto kern = gru2_kernel<256, KR>;
         allow_dynamic_lds((const void*)kern, lds);
-        hipLaunchKernelGGL(kern, dim3(16), dim3(384), lds, (hipStream_t)stream, gi, whh_t, bhh, out, (long)T, xb, err, force_agent);
+        hipLaunchKernelGGL(kern, dim3(32), dim3(384), lds, (hipStream_t)stream, gi, whh_t, bhh, out, (long)T, xb, err, force_agent);
     } else if (hidden == 64) {
         constexpr int KR = 48;
         const size_t lds = (size_t)(64 + 96 + (64 - KR) * 96) * sizeof(float);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(gru2_kernel<64, KR>), dim3(16), dim3(96), lds, (hipStream_t)stream, gi, whh_t, bhh, out,
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(gru2_kernel<64, KR>), dim3(32), dim3(96), lds, (hipStream_t)stream, gi, whh_t, bhh, out,
                            (long)T, xb, err, force_agent);
     } else {
         return fail(AICG_E_SHAPE, "aicg_gru_bidir_2wg: hidden size %d not instantiated (256, 64)", hidden);
