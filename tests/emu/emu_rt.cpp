@@ -217,7 +217,8 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
     const long total = (long)grid.x * grid.y * grid.z;
     if (total <= 0) return;
     unsigned hw = std::thread::hardware_concurrency();
-    if (hw == 0) hw = 4;
+    if (hw < 4) hw = 4;  // kernels whose workgroups wait for each other (2-workgroup GRU) need their partners running concurrently,
+                         // even if that means time-sharing one core
     const char* env = getenv("AICG_EMU_THREADS");
     if (env) hw = (unsigned)atoi(env);
     const long nthreads = total < (long)hw ? total : (long)hw;
