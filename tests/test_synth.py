@@ -101,3 +101,20 @@ def test_synth_variants_vs_reference_golden(dev, name, variant):
         o, _, (z, _, _, _) = net.infer(phone, torch.tensor([T]), torch.tensor([1]), noise_z=nz)
     assert rel_rms(z[0], torch.from_numpy(gold["z"])) < 1e-4
     assert rel_rms(o[0, 0], torch.from_numpy(gold["audio"])) < 1e-4
+
+
+@pytest.mark.parametrize("name,up,upk,sr", [("48k_v2", [12, 10, 2, 2], [24, 20, 4, 4], 48000),
+                                            ("32k_v2", [10, 8, 2, 2], [20, 16, 4, 4], 32000)])
+def test_other_sample_rate_geometries_match_oracle(dev, name, up, upk, sr):
+    """The 48 kHz / 32 kHz v2 voice models (configs/48k_v2.json:39-41, 32k_v2.json:39-41) use other upsampling factors and
+    transposed-conv kernels; same code path (GEMM + col2im, stride-phase noise convs), tiny channel counts."""
+    cfg = list(weights.SYNTH_CFG_TINY)
+    cfg[12], cfg[14], cfg[17] = up, upk, sr
+    T = 6
+    sd, (phone, pitch, f0, nz, ns), o, z, m_p, logs_p = _run(dev, cfg, T, seed=77)
+    upp = int(np.prod(up))
+    assert o.shape == (1, 1, T * upp)
+    with torch.no_grad():
+        ro, (rz, _, _, _) = synth.synth_infer(sd, cfg, phone, pitch, f0, torch.tensor([1]), nz, ns)
+    assert rel_rms(z, rz) < 1e-4
+    assert rel_rms(o, ro) < 1e-4
