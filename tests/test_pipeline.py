@@ -11,6 +11,7 @@ from aicovergen_amd.hubert import HubertModel
 from aicovergen_amd.infer_pack.models import SynthesizerTrnMs768NSFsid
 from aicovergen_amd.rmvpe import RMVPE
 from aicovergen_amd.vc_infer_pipeline import VC, Pipeline, change_rms
+from conftest import rel_rms
 from oracle import pipeline as opipe
 from oracle import weights
 from oracle.inputs import vocal_like
@@ -148,3 +149,50 @@ def test_device_post_processing_matches_oracle(dev):
     assert abs(ops.absmax(d).item() - np.abs(d.cpu().numpy()).max()) == 0
     sc = 32768 / (np.abs(want).max() / 0.99)
     assert np.array_equal(ops.to_int16(d, sc).cpu().numpy(), (d.cpu().numpy() * np.float32(sc)).astype(np.int16))
+
+
+def test_vc_chunk_v1_model_matches_oracle(dev):
+    """v1 voice models: HuBERT layer 9 + final_proj (768 -> 256) feeding SynthesizerTrnMs256NSFsid
+    (vc_infer_pipeline.py:398-406, models.py:532-640) -- the chunk-level path against the oracle's pieces."""
+    import torch.nn.functional as F
+    from aicovergen_amd.infer_pack.models import SynthesizerTrnMs256NSFsid
+    from oracle import hubert as ohub
+    from oracle import synth as osynth
+    nets = weights.small_model_set()
+    cfg = list(nets["synth_cfg"])
+    sd = weights.synth_state_dict(cfg, 31, phone_dim=256)
+    vc = VC(cfg[-1], _Cfg(dev.device))
+    hub = HubertModel(nets["hubert_sd"], nets["hubert_cfg"]).to(dev.device)
+    net_g = SynthesizerTrnMs256NSFsid(*cfg, is_half=False)
+    del net_g.enc_q
+    net_g.load_state_dict(sd, strict=False)
+    net_g.eval().to(dev.device)
+    audio0 = vocal_like(0.9, 16000, 3).astype(np.float64)
+    p_len = audio0.shape[0] // 160
+    torch.manual_seed(2)
+    pitchf = torch.where(torch.rand(1, p_len) > 0.3, 110 + 200 * torch.rand(1, p_len), torch.zeros(1, p_len))
+    pitch = (pitchf / 4).long().clamp(1, 255)
+    T = opipe.chunk_frames(audio0.shape[0])
+    upp = int(np.prod(cfg[12]))
+    nz, ns = opipe.chunk_noise(0, T, cfg[2], upp, 5)
+    sid = torch.tensor([0])
+    got = vc.vc(hub, net_g, sid.to(dev.device), audio0, pitch.to(dev.device), pitchf.to(dev.device), [0, 0, 0], None, None, 0,
+                "v1", 0.33, noise=(nz, ns[0]))
+    # oracle: the same steps with the reference's formulas
+    wav = torch.from_numpy(audio0).float().view(1, -1)
+    with torch.no_grad():
+        feats = ohub.final_proj(nets["hubert_sd"], ohub.extract_features(nets["hubert_sd"], nets["hubert_cfg"], wav, 9))
+    feats0 = feats.clone()
+    feats = F.interpolate(feats.permute(0, 2, 1), scale_factor=2).permute(0, 2, 1)
+    feats0 = F.interpolate(feats0.permute(0, 2, 1), scale_factor=2).permute(0, 2, 1)
+    n = min(p_len, feats.shape[1])
+    pf = pitchf[:, :n]
+    w = pf.clone()
+    w[pf > 0] = 1
+    w[pf < 1] = 0.33
+    w = w.unsqueeze(-1)
+    feats = feats[:, :n] * w + feats0[:, :n] * (1 - w)
+    with torch.no_grad():
+        ro, _ = osynth.synth_infer(sd, cfg, feats, pitch[:, :n], pf, sid, nz[:, :, :n], ns[:, :n * upp])
+    assert got.shape == (n * upp,)
+    assert rel_rms(torch.from_numpy(got), ro[0, 0]) < 1e-4
