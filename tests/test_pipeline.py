@@ -196,3 +196,29 @@ def test_vc_chunk_v1_model_matches_oracle(dev):
         ro, _ = osynth.synth_infer(sd, cfg, feats, pitch[:, :n], pf, sid, nz[:, :, :n], ns[:, :n * upp])
     assert got.shape == (n * upp,)
     assert rel_rms(torch.from_numpy(got), ro[0, 0]) < 1e-4
+
+
+def test_pipeline_without_f0_model(dev):
+    """`_nono` voice models (if_f0 = 0, plain HiFi-GAN generator: models.py:754-955): no f0 branch, no protect blend."""
+    from aicovergen_amd.infer_pack.models import SynthesizerTrnMs768NSFsid_nono
+    nets = weights.small_model_set()
+    cfg = list(nets["synth_cfg"])
+    sd = weights.synth_state_dict(cfg, 41, f0=False)
+    vc = VC(cfg[-1], _Cfg(dev.device))
+    hub = HubertModel(nets["hubert_sd"], nets["hubert_cfg"]).to(dev.device)
+    net_g = SynthesizerTrnMs768NSFsid_nono(*cfg)
+    del net_g.enc_q
+    net_g.load_state_dict(sd, strict=False)
+    net_g.eval().to(dev.device)
+    audio = vocal_like(1.0, 16000, 8)
+    upp = int(np.prod(cfg[12]))
+
+    def noise_fn(ci, s, e):
+        nz, _ = opipe.chunk_noise(ci, opipe.chunk_frames(e - s), cfg[2], upp, 3)
+        return nz, None
+
+    outs = [vc.pipeline(hub, net_g, 0, audio, "x.wav", [0, 0, 0], 0, "rmvpe", "", 0.5, 0, 3, cfg[-1], 0, 1, "v2", 0.5, 128,
+                        noise_fn=noise_fn) for _ in range(2)]
+    assert outs[0].dtype == np.int16 and np.array_equal(outs[0], outs[1])
+    assert abs(len(outs[0]) / cfg[-1] - 1.0) < 0.06 and np.abs(outs[0]).max() > 50
+    assert not hasattr(vc, "model_rmvpe")     # the f0 estimator is never built for these models
