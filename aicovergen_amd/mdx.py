@@ -95,16 +95,17 @@ class MDX:
         self.process = lambda spec: self.net(spec).cpu().numpy()
         self.prog = None
 
+    _HASH_TAIL = 10000 * 1024
+
     @staticmethod
     def get_hash(model_path):
-        """md5 of the last 10 000 KiB of the file (whole file if smaller) (mdx.py:81-90)."""
-        try:
-            with open(model_path, 'rb') as f:
-                f.seek(- 10000 * 1024, 2)
-                model_hash = hashlib.md5(f.read()).hexdigest()
-        except Exception:
-            model_hash = hashlib.md5(open(model_path, 'rb').read()).hexdigest()
-        return model_hash
+        """Key into model_data.json: md5 of the file's last 10 000 KiB, or of the whole file when it is shorter than that
+        (the reference seeks from the end and falls back on the OSError, mdx.py:81-90)."""
+        size = os.path.getsize(model_path)
+        with open(model_path, "rb") as fh:
+            if size > MDX._HASH_TAIL:
+                fh.seek(size - MDX._HASH_TAIL)
+            return hashlib.md5(fh.read()).hexdigest()
 
     @staticmethod
     def segment(wave, combine=True, chunk_size=DEFAULT_CHUNK_SIZE, margin_size=DEFAULT_MARGIN_SIZE):
@@ -259,46 +260,47 @@ class MDX:
         return parts[0] if len(parts) == 1 else torch.cat(parts, dim=-1)
 
 
+def _stem_path(output_dir, filename, stem):
+    base = os.path.splitext(os.path.basename(filename))[0]
+    return os.path.join(output_dir, "%s_%s.wav" % (base, stem))
+
+
 def run_mdx(model_params, output_dir, model_path, filename, exclude_main=False, exclude_inversion=False, suffix=None,
             invert_suffix=None, denoise=False, keep_orig=True, m_threads=2):
-    """Drop-in for reference src/mdx.py:238-287 (same arguments, same files written, same return value)."""
-    device = torch.device('cuda:0') if torch.cuda.is_available() else torch.device('cpu')
-    device_properties = torch.cuda.get_device_properties(device)
-    vram_gb = device_properties.total_memory / 1024 ** 3
-    m_threads = 1 if vram_gb < 8 else 2
+    """File in -> stem files out, with the arguments, file names and return value of reference src/mdx.py:238-287:
+    model hash -> `model_params` entry -> MDXModel; stereo 44.1 kHz load; peak-normalise; separate (optionally as the odd part
+    0.5 * (f(x) - f(-x))); undo the normalisation; write `<name>_<stem>.wav` and the inverted stem
+    `-out * compensation + normalised input` (the reference adds the NORMALISED wave, mdx.py:280); PCM-16 like soundfile."""
+    on_gpu = torch.cuda.is_available()
+    device = torch.device("cuda:0" if on_gpu else "cpu")
+    # the reference halves the thread (= segment) count on cards under 8 GB; it queries the device unconditionally
+    vram_gb = torch.cuda.get_device_properties(device).total_memory / 1024 ** 3
+    m_threads = 2 if vram_gb >= 8 else 1
 
-    model_hash = MDX.get_hash(model_path)
-    mp = model_params.get(model_hash)
-    model = MDXModel(device, dim_f=mp["mdx_dim_f_set"], dim_t=2 ** mp["mdx_dim_t_set"], n_fft=mp["mdx_n_fft_scale_set"],
-                     stem_name=mp["primary_stem"], compensation=mp["compensate"])
-    mdx_sess = MDX(model_path, model)
+    entry = model_params.get(MDX.get_hash(model_path))
+    model = MDXModel(device, dim_f=entry["mdx_dim_f_set"], dim_t=2 ** entry["mdx_dim_t_set"], n_fft=entry["mdx_n_fft_scale_set"],
+                     stem_name=entry["primary_stem"], compensation=entry["compensate"])
+    session = MDX(model_path, model)
+
     wave, sr = audio_io.load_wav(filename, 44100, mono=False)
     if wave.shape[0] == 1:
         wave = np.concatenate([wave, wave], 0)
-    # normalizing input wave gives better output
     peak = max(np.max(wave), abs(np.min(wave)))
     wave /= peak
-    wave_processed = run_mdx_arrays(mdx_sess, wave, denoise, m_threads)
-    # return to previous peak
-    wave_processed *= peak
-    stem_name = model.stem_name if suffix is None else suffix
+    separated = run_mdx_arrays(session, wave, denoise, m_threads) * peak
 
-    main_filepath = None
+    primary = suffix if suffix is not None else model.stem_name
+    main_filepath = invert_filepath = None
     if not exclude_main:
-        main_filepath = os.path.join(output_dir, f"{os.path.basename(os.path.splitext(filename)[0])}_{stem_name}.wav")
-        audio_io.write_wav_pcm16(main_filepath, wave_processed.T, sr)
-
-    invert_filepath = None
+        main_filepath = _stem_path(output_dir, filename, primary)
+        audio_io.write_wav_pcm16(main_filepath, separated.T, sr)
     if not exclude_inversion:
-        diff_stem_name = stem_naming.get(stem_name) if invert_suffix is None else invert_suffix
-        stem_name = f"{stem_name}_diff" if diff_stem_name is None else diff_stem_name
-        invert_filepath = os.path.join(output_dir, f"{os.path.basename(os.path.splitext(filename)[0])}_{stem_name}.wav")
-        audio_io.write_wav_pcm16(invert_filepath, (-wave_processed.T * model.compensation) + wave.T, sr)
-
+        other = invert_suffix if invert_suffix is not None else stem_naming.get(primary)
+        invert_filepath = _stem_path(output_dir, filename, other if other is not None else primary + "_diff")
+        audio_io.write_wav_pcm16(invert_filepath, wave.T - separated.T * model.compensation, sr)
     if not keep_orig:
         os.remove(filename)
-
-    del mdx_sess, wave_processed, wave
+    del session, separated, wave
     gc.collect()
     return main_filepath, invert_filepath
 
