@@ -1,6 +1,7 @@
 // Error plumbing and version entry points of the C ABI (include/aicg.h).
 #include "common.h"
 
+#include <cstdint>
 #include <mutex>
 #include <unordered_map>
 
@@ -8,9 +9,11 @@ namespace aicg {
 void allow_dynamic_lds(const void* kernel, size_t bytes) {
     if (bytes <= 64 * 1024) return;
     static std::mutex mu;
-    static std::unordered_map<const void*, size_t> granted;
+    static std::unordered_map<unsigned long long, size_t> granted;  // (device, kernel): the attribute is per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(mu);
-    size_t& g = granted[kernel];
+    size_t& g = granted[((unsigned long long)(uintptr_t)kernel) ^ ((unsigned long long)(dev + 1) << 56)];
     if (g >= bytes) return;
     // grant the whole 160 KB of a gfx950 CU at once: one runtime call per kernel for the lifetime of the process
     const size_t want = 160 * 1024;

@@ -52,6 +52,7 @@ inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStrea
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 inline hipError_t hipDeviceSynchronize() { return 0; }
 inline hipError_t hipFuncSetAttribute(const void*, int, int) { return 0; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
 #define hipFuncAttributeMaxDynamicSharedMemorySize 8
 
 // ---- vector types ------------------------------------------------------------------------------
