@@ -1202,14 +1202,21 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
             if (rc <= 0) return rc;
         }
     }
-    if (BM == 160 && blocks(160, 128) >= want) return launch_conv<160, 128, 1, 4>(p, st);
+    // single-role kernels: layers the wave-specialised form could not stage.  A patch that is too large even here (wide
+    // strided / dilated 2-D windows) is retried on the narrowest tile (64 positions) before giving up.
     static const bool eight = getenv("AICG_CONV_8WAVE") ? atoi(getenv("AICG_CONV_8WAVE")) != 0 : true;
-    if (BM == 128 && blocks(128, 128) >= want) return eight ? launch_conv<128, 128, 2, 4>(p, st) : launch_conv<128, 128, 2, 2>(p, st);
-    if (BM == 96 && blocks(96, 128) >= want) return launch_conv<96, 128, 1, 4>(p, st);
-    if (M > 32) {
-        if (blocks(64, 128) >= want) return launch_conv<64, 128, 2, 2>(p, st);
-        if (blocks(64, 64) >= want || M > 64) return launch_conv<64, 64, 2, 2>(p, st);
-    }
-    if (blocks(32, 256) >= want) return launch_conv<32, 256, 1, 4>(p, st);
-    return launch_conv<32, 128, 1, 4>(p, st);
+    auto single_role = [&]() -> int {
+        if (BM == 160 && blocks(160, 128) >= want) return launch_conv<160, 128, 1, 4>(p, st);
+        if (BM == 128 && blocks(128, 128) >= want) return eight ? launch_conv<128, 128, 2, 4>(p, st) : launch_conv<128, 128, 2, 2>(p, st);
+        if (BM == 96 && blocks(96, 128) >= want) return launch_conv<96, 128, 1, 4>(p, st);
+        if (M > 32) {
+            if (blocks(64, 128) >= want) return launch_conv<64, 128, 2, 2>(p, st);
+            if (blocks(64, 64) >= want || M > 64) return launch_conv<64, 64, 2, 2>(p, st);
+        }
+        if (blocks(32, 256) >= want) return launch_conv<32, 256, 1, 4>(p, st);
+        return launch_conv<32, 128, 1, 4>(p, st);
+    };
+    int rc = single_role();
+    if (rc == AICG_E_LDS) rc = launch_conv<64, 64, 2, 2>(p, st);
+    return rc;
 }
