@@ -55,10 +55,15 @@ def build_hip(force=False, verbose=True):
             if rc != 0:
                 raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), log))
     if jobs or force or not os.path.exists(OUT):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
-        r = subprocess.run(cmd, capture_output=True, text=True)
+        # link inside build/ (clang-offload-bundler drops its per-object temporaries next to the output), then move
+        tmp = os.path.join(OBJ_DIR, "libaicg_hip.so")
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=OBJ_DIR)
         if r.returncode != 0:
             raise RuntimeError("link failed: %s\n%s" % (" ".join(cmd), r.stdout + r.stderr))
+        os.replace(tmp, OUT)
+        for f in glob.glob(os.path.join(OBJ_DIR, "libaicg_hip.so.*")) + glob.glob(os.path.join(HERE, "libaicg_hip.so.*")):
+            os.remove(f)
     return OUT
 
 

@@ -45,8 +45,10 @@ __global__ void __launch_bounds__(256) argmin_abs_f64_kernel(const double* __res
 
 __device__ __forceinline__ long reflect_index(long p, long pad, long n) {
     long i = p - pad;               // np.pad(mode="reflect"): ... x2 x1 | x0 x1 ... x(n-1) | x(n-2) ...
-    if (i < 0) i = -i;
-    if (i >= n) i = 2 * (n - 1) - i;
+    if (n == 1) return 0;
+    const long period = 2 * (n - 1);  // repeated reflection (pad longer than the signal: clips of <= 0.5 s) has this period
+    if (i < 0 || i >= period) { i %= period; if (i < 0) i += period; }
+    if (i >= n) i = period - i;
     return i;
 }
 
@@ -127,7 +129,7 @@ extern "C" int aicg_argmin_abs_f64(const double* x, const int64_t* starts, const
 
 extern "C" int aicg_frame_rms(const void* x, int is_f64, double* out, int64_t n, int frame_length, int hop_length, void* stream) {
     if (!x || !out) return fail(AICG_E_ARG, "aicg_frame_rms: null pointer");
-    if (n <= frame_length / 2) return fail(AICG_E_SHAPE, "aicg_frame_rms: signal shorter than the reflect padding");
+    if (n <= 0 || frame_length <= 0 || hop_length <= 0) return fail(AICG_E_SHAPE, "aicg_frame_rms: empty signal or bad framing");
     const long n_frames = 1 + n / hop_length;  // 1 + (n + 2*(frame/2) - frame) / hop with an even frame
     if (is_f64)
         hipLaunchKernelGGL(HIP_KERNEL_NAME(frame_rms_kernel<double>), dim3((unsigned)n_frames), dim3(256), 0, (hipStream_t)stream,

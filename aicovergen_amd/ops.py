@@ -3,6 +3,7 @@ functions validate shapes, allocate outputs with torch, and hand raw device poin
 stream to libaicg_hip.so."""
 import math
 import os
+import threading
 
 import numpy as np
 import torch
@@ -20,10 +21,15 @@ def _stream(t):
     return 0
 
 
+_tls = threading.local()
+
+
 def _check(*tensors):
     """All tensors must be fp32/int, contiguous where required by the caller, and live where the bound
-    library executes: HIP device memory for the product library, host memory for the test emulator."""
+    library executes: HIP device memory of ONE device for the product library, host memory for the test emulator.
+    Remembers that device for the launch that follows (`_call`)."""
     be = _lib.backend()
+    dev = None
     for t in tensors:
         if t is None:
             continue
@@ -31,6 +37,23 @@ def _check(*tensors):
             raise RuntimeError("aicovergen_amd: tensor on %s, but the HIP kernels need device memory" % t.device)
         if be == "emu" and t.is_cuda:
             raise RuntimeError("emulator backend needs host tensors")
+        if t.is_cuda:
+            if dev is None:
+                dev = t.device.index
+            elif dev != t.device.index:
+                raise RuntimeError("aicovergen_amd: operands on different devices (cuda:%d and cuda:%d)" % (dev, t.device.index))
+    _tls.dev = dev
+
+
+def _call(name, *args):
+    """_lib.call with the operands' device made current: the C ABI launches on the calling thread's current HIP device, and
+    the stream / pointers handed over belong to the tensors' device (MDX(processor=1), Config('cuda:1') never call
+    torch.cuda.set_device)."""
+    dev = getattr(_tls, "dev", None)
+    if dev is not None and dev != torch.cuda.current_device():
+        with torch.cuda.device(dev):
+            return _lib.call(name, *args)
+    return _lib.call(name, *args)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -75,7 +98,7 @@ def stft(x, n_fft, hop, n_bins_out=None, frame_major=False, window=None):
     else:
         out = torch.empty((n_sig, 2, nb, n_frames), dtype=torch.float32, device=x.device)
         o_bin, o_frame = n_frames, 1
-    _lib.call("aicg_stft", _ptr(x), _ptr(out), _ptr(window), _ptr(tw_half), _ptr(tw_full), n_sig, L, n_fft, hop,
+    _call("aicg_stft", _ptr(x), _ptr(out), _ptr(window), _ptr(tw_half), _ptr(tw_full), n_sig, L, n_fft, hop,
               n_frames, nb, 2 * nb * n_frames, nb * n_frames, o_bin, o_frame, _stream(x))
     return out
 
@@ -97,9 +120,9 @@ def istft(spec, n_fft, hop, length, frame_major=False, window=None):
     frames = torch.empty((n_sig, n_frames, n_fft), dtype=torch.float32, device=spec.device)
     out = torch.empty((n_sig, length), dtype=torch.float32, device=spec.device)
     st = _stream(spec)
-    _lib.call("aicg_istft_frames", _ptr(spec), _ptr(frames), _ptr(window), _ptr(tw_half), _ptr(tw_full), n_sig,
+    _call("aicg_istft_frames", _ptr(spec), _ptr(frames), _ptr(window), _ptr(tw_half), _ptr(tw_full), n_sig,
               n_fft, n_frames, nb, 2 * nb * n_frames, nb * n_frames, i_bin, i_frame, st)
-    _lib.call("aicg_istft_ola", _ptr(frames), _ptr(window), _ptr(out), n_sig, length, n_fft, hop, n_frames, st)
+    _call("aicg_istft_ola", _ptr(frames), _ptr(window), _ptr(out), n_sig, length, n_fft, hop, n_frames, st)
     return out
 
 
@@ -251,7 +274,7 @@ def conv(x, pc, res=None, out=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NON
     if prof is not None and x.is_cuda:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.call("aicg_conv_forward", ctypes.addressof(d), _ptr(x4), _ptr(pc.w), _ptr(b), _ptr(r4), _ptr(o4), _stream(x))
+    _call("aicg_conv_forward", ctypes.addressof(d), _ptr(x4), _ptr(pc.w), _ptr(b), _ptr(r4), _ptr(o4), _stream(x))
     if prof is not None and x.is_cuda:
         e1.record()
         prof.events.append((e0, e1))
@@ -312,7 +335,7 @@ def conv_transpose(x, pt, out=None, add=None, pre_act=ACT_NONE, pre_slope=0.0, a
         assert a4.shape == o4.shape and (a4.stride(3) == 1 or wo == 1)
     _check(cols, out, add, pt.bias)
     asn, asc, ash = (a4.stride(0), a4.stride(1), a4.stride(2)) if a4 is not None else (0, 0, 0)
-    _lib.call("aicg_col2im", _ptr(cols), _ptr(pt.bias), _ptr(a4), _ptr(o4), n, pt.cout, h, w, ho, wo, pt.kh, pt.kw,
+    _call("aicg_col2im", _ptr(cols), _ptr(pt.bias), _ptr(a4), _ptr(o4), n, pt.cout, h, w, ho, wo, pt.kh, pt.kw,
               pt.stride[0], pt.stride[1], pt.padding[0], pt.padding[1], act, act_slope,
               o4.stride(0), o4.stride(1), o4.stride(2), asn, asc, ash, _stream(x))
     if mul is not None:
@@ -332,7 +355,7 @@ def sine_source(f0, noise, upp, sr, lin_w, lin_b, sine_amp=0.1, noise_std=0.003)
     _check(f0, noise)
     prefix = torch.empty(t, dtype=torch.float64, device=f0.device)
     out = torch.empty(t * upp, dtype=torch.float32, device=f0.device)
-    _lib.call("aicg_sine_source", _ptr(f0), _ptr(noise), _ptr(prefix), _ptr(out), t, int(upp), float(sr), sine_amp,
+    _call("aicg_sine_source", _ptr(f0), _ptr(noise), _ptr(prefix), _ptr(out), t, int(upp), float(sr), sine_amp,
               noise_std, float(lin_w), float(lin_b), _stream(f0))
     return out
 
@@ -345,7 +368,7 @@ def gate_tanh_sigmoid(a, out=None):
         out = torch.empty((n, c2 // 2, t), dtype=torch.float32, device=a.device)
     assert out.is_contiguous()
     _check(a, out)
-    _lib.call("aicg_gate_tanh_sigmoid", _ptr(a), _ptr(out), n, c2 // 2, t, _stream(a))
+    _call("aicg_gate_tanh_sigmoid", _ptr(a), _ptr(out), n, c2 // 2, t, _stream(a))
     return out
 
 
@@ -356,7 +379,7 @@ def prior_sample(stats, noise, scale):
     assert stats.shape[1] == 2 * c and stats.shape[2] == t
     out = torch.empty_like(noise)
     _check(stats, noise)
-    _lib.call("aicg_prior_sample", _ptr(stats), _ptr(noise), _ptr(out), c, t, float(scale), _stream(stats))
+    _call("aicg_prior_sample", _ptr(stats), _ptr(noise), _ptr(out), c, t, float(scale), _stream(stats))
     return out
 
 
@@ -370,7 +393,7 @@ def feats_prepare(feats, t_out, feats0=None, pitchf=None, protect=0.5):
         pitchf = pitchf.contiguous().float()
         assert pitchf.numel() >= t_out
     _check(feats, feats0, pitchf)
-    _lib.call("aicg_feats_prepare", _ptr(feats), _ptr(feats0), _ptr(pitchf), _ptr(out), th, c, int(t_out), float(protect),
+    _call("aicg_feats_prepare", _ptr(feats), _ptr(feats0), _ptr(pitchf), _ptr(out), th, c, int(t_out), float(protect),
               _stream(feats))
     return out
 
@@ -384,7 +407,7 @@ def layernorm_ct(x, gamma, beta, res=None, out=None, eps=1e-5):
     if res is not None:
         assert res.is_contiguous() and res.shape == x.shape
     _check(x, res, gamma, beta, out)
-    _lib.call("aicg_layernorm_ct", _ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(out), n, c, t, float(eps), c * t, c * t,
+    _call("aicg_layernorm_ct", _ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(out), n, c, t, float(eps), c * t, c * t,
               c * t, _stream(x))
     return out
 
@@ -395,7 +418,7 @@ def rownorm_act(x, gamma, beta, act=ACT_NONE, eps=1e-5, out=None):
     if out is None:
         out = torch.empty_like(x)
     _check(x, gamma, beta, out)
-    _lib.call("aicg_rownorm_act", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), x.shape[0], x.shape[1], float(eps), act,
+    _call("aicg_rownorm_act", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), x.shape[0], x.shape[1], float(eps), act,
               _stream(x))
     return out
 
@@ -417,14 +440,14 @@ def attention(q, k, v, n_heads, relk=None, relv_emb=None, window=0, scale=1.0, n
     splits = max(1, min(4, -(-t // 32), -(-1024 // blocks))) if n_splits is None else n_splits  # > 4: the merge pass costs more than it fills
     if splits > 1:
         scratch = torch.empty(splits * n_heads * (d + 2) * t, dtype=torch.float32, device=q.device)
-        _lib.call("aicg_attention_split", _ptr(q), _ptr(k), _ptr(v), _ptr(relk), _ptr(o), _ptr(lse), t, n_heads, d, window,
+        _call("aicg_attention_split", _ptr(q), _ptr(k), _ptr(v), _ptr(relk), _ptr(o), _ptr(lse), t, n_heads, d, window,
                   q.stride(0), k.stride(0), v.stride(0), o.stride(0), float(scale), splits, _ptr(scratch), st)
     else:
-        _lib.call("aicg_attention", _ptr(q), _ptr(k), _ptr(v), _ptr(relk), _ptr(o), _ptr(lse), t, n_heads, d, window,
+        _call("aicg_attention", _ptr(q), _ptr(k), _ptr(v), _ptr(relk), _ptr(o), _ptr(lse), t, n_heads, d, window,
                   q.stride(0), k.stride(0), v.stride(0), o.stride(0), float(scale), st)
     if relv_emb is not None:
         relv_emb = relv_emb.contiguous()
-        _lib.call("aicg_attention_relv", _ptr(q), _ptr(k), _ptr(relk), _ptr(relv_emb), _ptr(lse), _ptr(o), t, n_heads, d,
+        _call("aicg_attention_relv", _ptr(q), _ptr(k), _ptr(relk), _ptr(relv_emb), _ptr(lse), _ptr(o), t, n_heads, d,
                   window, q.stride(0), k.stride(0), o.stride(0), float(scale), st)
     return o
 
@@ -439,7 +462,7 @@ def complex_abs(re, im):
     assert re.is_contiguous() and im.is_contiguous() and re.shape == im.shape
     out = torch.empty_like(re)
     _check(re, im)
-    _lib.call("aicg_complex_abs", _ptr(re), _ptr(im), _ptr(out), re.numel(), _stream(re))
+    _call("aicg_complex_abs", _ptr(re), _ptr(im), _ptr(out), re.numel(), _stream(re))
     return out
 
 
@@ -449,7 +472,7 @@ def channel_affine(x, scale, shift, act=ACT_NONE):
     hw = x.numel() // (n * c)
     out = torch.empty_like(x)
     _check(x, scale, shift)
-    _lib.call("aicg_channel_affine", _ptr(x), _ptr(scale), _ptr(shift), _ptr(out), n, c, hw, act, _stream(x))
+    _call("aicg_channel_affine", _ptr(x), _ptr(scale), _ptr(shift), _ptr(out), n, c, hw, act, _stream(x))
     return out
 
 
@@ -458,7 +481,7 @@ def avgpool2x2(x):
     assert x.stride(3) == 1
     out = torch.empty((n, c, h // 2, w // 2), dtype=torch.float32, device=x.device)
     _check(x)
-    _lib.call("aicg_avgpool2x2", _ptr(x), _ptr(out), n, c, h, w, x.stride(0), x.stride(1), x.stride(2), _stream(x))
+    _call("aicg_avgpool2x2", _ptr(x), _ptr(out), n, c, h, w, x.stride(0), x.stride(1), x.stride(2), _stream(x))
     return out
 
 
@@ -468,13 +491,21 @@ GRU_TWO_WORKGROUPS = os.environ.get("AICG_GRU_2WG", "1") != "0"
 _gru_pending = []
 
 
-def gru_check_pending():
-    """Raise if any two-workgroup GRU launch since the last call reported a partner-exchange timeout.  Call after the
-    stream that ran them has been drained (RMVPE does, right after copying f0 to the host)."""
+def gru_timed_out():
+    """True if any two-workgroup GRU launch since the last call reported a partner-exchange timeout (the partner workgroup
+    was not co-resident in time: a busy or shared GPU).  Call after the stream that ran them has been drained.  The result
+    of such a launch is invalid; callers recompute with the single-workgroup kernel (`gru_bidir(two_workgroups=False)`)."""
     flags, _gru_pending[:] = list(_gru_pending), []
+    bad = False
     for f in flags:
-        if int(f.item()) != 0:
-            raise RuntimeError("aicg_gru_bidir_2wg: partner workgroup exchange timed out")
+        bad = bad or int(f.item()) != 0
+    return bad
+
+
+def gru_check_pending():
+    """Raise if a two-workgroup GRU launch timed out (for callers that cannot recompute)."""
+    if gru_timed_out():
+        raise RuntimeError("aicg_gru_bidir_2wg: partner workgroup exchange timed out")
 
 
 def gru_bidir(gi, whh_t, bhh, hidden, two_workgroups=None):
@@ -486,14 +517,15 @@ def gru_bidir(gi, whh_t, bhh, hidden, two_workgroups=None):
     _check(gi, whh_t, bhh)
     if GRU_TWO_WORKGROUPS if two_workgroups is None else two_workgroups:
         scratch = torch.empty(32 * hidden + 64, dtype=torch.uint8, device=gi.device)
-        _lib.call("aicg_gru_bidir_2wg", _ptr(gi), _ptr(whh_t), _ptr(bhh), _ptr(out), hidden, t, _ptr(scratch), _stream(gi))
+        _call("aicg_gru_bidir_2wg", _ptr(gi), _ptr(whh_t), _ptr(bhh), _ptr(out), hidden, t, _ptr(scratch), _stream(gi))
         # the kernel's exchange-timeout flag is read back lazily (gru_check_pending): an .item() here would park the host
         # until the recurrence ends, which is exactly the time pipeline() wants to spend queueing HuBERT work
         _gru_pending.append(scratch[32 * hidden: 32 * hidden + 4].view(torch.int32))
         if len(_gru_pending) > 16:  # a caller that never checks: bound the backlog (this one synchronises)
-            gru_check_pending()
+            if gru_timed_out():  # recompute on the kernel that needs no co-residency
+                _call("aicg_gru_bidir", _ptr(gi), _ptr(whh_t), _ptr(bhh), _ptr(out), hidden, t, _stream(gi))
         return out
-    _lib.call("aicg_gru_bidir", _ptr(gi), _ptr(whh_t), _ptr(bhh), _ptr(out), hidden, t, _stream(gi))
+    _call("aicg_gru_bidir", _ptr(gi), _ptr(whh_t), _ptr(bhh), _ptr(out), hidden, t, _stream(gi))
     return out
 
 
@@ -505,7 +537,7 @@ def salience_decode(salience, thred=0.03, want_center=False):
     f0 = torch.empty(t, dtype=torch.float64, device=salience.device)
     center = torch.empty(t, dtype=torch.int32, device=salience.device) if want_center else None
     _check(salience)
-    _lib.call("aicg_salience_decode", _ptr(salience), _ptr(cents), _ptr(f0), _ptr(center), t, nb, float(thred), _stream(salience))
+    _call("aicg_salience_decode", _ptr(salience), _ptr(cents), _ptr(f0), _ptr(center), t, nb, float(thred), _stream(salience))
     return (cents, f0, center) if want_center else (cents, f0)
 
 
@@ -515,7 +547,7 @@ def f0_coarse(f0, factor, mel_min, mel_max):
     out = torch.empty_like(f0)
     coarse = torch.empty(f0.shape, dtype=torch.int64, device=f0.device)
     _check(f0)
-    _lib.call("aicg_f0_coarse", _ptr(f0), float(factor), _ptr(out), _ptr(coarse), f0.numel(), float(mel_min), float(mel_max),
+    _call("aicg_f0_coarse", _ptr(f0), float(factor), _ptr(out), _ptr(coarse), f0.numel(), float(mel_min), float(mel_max),
               _stream(f0))
     return out, coarse
 
@@ -534,7 +566,7 @@ def linear_last(x, weight, bias=None, ch_scale=None, ch_shift=None, act=ACT_NONE
     if res is not None:
         assert res.is_contiguous() and res.shape == out.shape
     _check(x, weight, bias, ch_scale, ch_shift, res, out)
-    _lib.call("aicg_gemm_nt", _ptr(x), _ptr(weight), _ptr(bias), _ptr(ch_scale), _ptr(ch_shift), _ptr(res), _ptr(out),
+    _call("aicg_gemm_nt", _ptr(x), _ptr(weight), _ptr(bias), _ptr(ch_scale), _ptr(ch_shift), _ptr(res), _ptr(out),
               b * c * t, f, o, f, f, o, o, t, c, act, _stream(x))
     return out
 
@@ -544,7 +576,7 @@ def mul(a, b, out=None):
     if out is None:
         out = torch.empty_like(a)
     _check(a, b, out)
-    _lib.call("aicg_mul", _ptr(a), _ptr(b), _ptr(out), a.numel(), _stream(a))
+    _call("aicg_mul", _ptr(a), _ptr(b), _ptr(out), a.numel(), _stream(a))
     return out
 
 
@@ -554,7 +586,7 @@ def axpbypcz(a, alpha, b=None, beta=0.0, c=None, gamma=0.0, out=None):
     if out is None:
         out = torch.empty_like(a)
     _check(a, b, c, out)
-    _lib.call("aicg_axpbypcz", _ptr(a), float(alpha), _ptr(b), float(beta), _ptr(c), float(gamma), _ptr(out), a.numel(),
+    _call("aicg_axpbypcz", _ptr(a), float(alpha), _ptr(b), float(beta), _ptr(c), float(gamma), _ptr(out), a.numel(),
               _stream(a))
     return out
 
@@ -568,7 +600,7 @@ def box_sum_f64(x, n, window):
     assert x.dtype == torch.float64 and x.numel() >= n + window - 1
     out = torch.empty(n, dtype=torch.float64, device=x.device)
     _check(x)
-    _lib.call("aicg_box_sum_f64", _ptr(x), _ptr(out), n, window, _stream(x))
+    _call("aicg_box_sum_f64", _ptr(x), _ptr(out), n, window, _stream(x))
     return out
 
 
@@ -579,7 +611,7 @@ def argmin_abs_f64(x, starts, lens):
     ln = torch.tensor(list(lens), dtype=torch.int64, device=x.device)
     out = torch.empty(len(st), dtype=torch.int64, device=x.device)
     _check(x)
-    _lib.call("aicg_argmin_abs_f64", _ptr(x), _ptr(st), _ptr(ln), _ptr(out), len(st), _stream(x))
+    _call("aicg_argmin_abs_f64", _ptr(x), _ptr(st), _ptr(ln), _ptr(out), len(st), _stream(x))
     return out
 
 
@@ -590,14 +622,14 @@ def frame_rms(x, frame_length, hop_length):
     n = x.numel()
     out = torch.empty(1 + n // hop_length, dtype=torch.float64, device=x.device)
     _check(x)
-    _lib.call("aicg_frame_rms", _ptr(x), 1 if x.dtype == torch.float64 else 0, _ptr(out), n, frame_length, hop_length, _stream(x))
+    _call("aicg_frame_rms", _ptr(x), 1 if x.dtype == torch.float64 else 0, _ptr(out), n, frame_length, hop_length, _stream(x))
     return out
 
 
 def rms_mix_(data, rms1, rms2, rate):
     assert data.is_contiguous() and data.dtype == torch.float32
     _check(data, rms1, rms2)
-    _lib.call("aicg_rms_mix", _ptr(data), data.numel(), _ptr(rms1), rms1.numel(), _ptr(rms2), rms2.numel(), float(rate),
+    _call("aicg_rms_mix", _ptr(data), data.numel(), _ptr(rms1), rms1.numel(), _ptr(rms2), rms2.numel(), float(rate),
               _stream(data))
     return data
 
@@ -606,7 +638,7 @@ def absmax(x):
     assert x.is_contiguous() and x.dtype == torch.float32
     out = torch.zeros(1, dtype=torch.float32, device=x.device)
     _check(x)
-    _lib.call("aicg_absmax", _ptr(x), x.numel(), _ptr(out), _stream(x))
+    _call("aicg_absmax", _ptr(x), x.numel(), _ptr(out), _stream(x))
     return out
 
 
@@ -614,7 +646,7 @@ def to_int16(x, scale):
     assert x.is_contiguous() and x.dtype == torch.float32
     out = torch.empty(x.shape, dtype=torch.int16, device=x.device)
     _check(x)
-    _lib.call("aicg_to_int16", _ptr(x), _ptr(out), x.numel(), float(scale), _stream(x))
+    _call("aicg_to_int16", _ptr(x), _ptr(out), x.numel(), float(scale), _stream(x))
     return out
 
 
@@ -625,7 +657,7 @@ def frame_normalize(frames):
     assert frames.is_contiguous() and frames.dim() == 2
     out = torch.empty_like(frames)
     _check(frames)
-    _lib.call("aicg_frame_normalize", _ptr(frames), _ptr(out), frames.shape[0], frames.shape[1], _stream(frames))
+    _call("aicg_frame_normalize", _ptr(frames), _ptr(out), frames.shape[0], frames.shape[1], _stream(frames))
     return out
 
 
@@ -635,7 +667,7 @@ def affine_maxpool2(x, scale, shift):
     n, c, w = x.shape
     out = torch.empty((n, c, w // 2), dtype=torch.float32, device=x.device)
     _check(x, scale, shift)
-    _lib.call("aicg_affine_maxpool2", _ptr(x), _ptr(scale), _ptr(shift), _ptr(out), n, c, w, _stream(x))
+    _call("aicg_affine_maxpool2", _ptr(x), _ptr(scale), _ptr(shift), _ptr(out), n, c, w, _stream(x))
     return out
 
 
@@ -648,6 +680,6 @@ def crepe_viterbi(probs, seq_len, bin_lo, bin_hi):
     ptr = torch.empty((n_seq, ms, nb), dtype=torch.int16, device=probs.device)
     bins = torch.zeros((n_seq, ms), dtype=torch.int64, device=probs.device)
     _check(probs)
-    _lib.call("aicg_crepe_viterbi", _ptr(probs), _ptr(sl), _ptr(logp), _ptr(ptr), _ptr(bins), n_seq, nb, ms, int(bin_lo),
+    _call("aicg_crepe_viterbi", _ptr(probs), _ptr(sl), _ptr(logp), _ptr(ptr), _ptr(bins), n_seq, nb, ms, int(bin_lo),
               int(bin_hi), _stream(probs))
     return bins

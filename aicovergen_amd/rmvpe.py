@@ -128,7 +128,7 @@ class E2E:
         self.bhh = torch.cat([sd["fc.0.gru.bias_hh_l0"], sd["fc.0.gru.bias_hh_l0_reverse"]]).float().contiguous().to(dev)
         self.fc = ops.PackedConv(sd["fc.1.weight"].float(), sd["fc.1.bias"], device=dev)
 
-    def __call__(self, mel):
+    def __call__(self, mel, two_workgroups=None):
         """mel (1, 128, T) with T % 32 == 0 -> salience (1, T, 360)."""
         T = mel.shape[-1]
         x = mel[0].t().contiguous().view(1, 1, T, mel.shape[1])          # mel.transpose(-1,-2).unsqueeze(1)
@@ -155,7 +155,7 @@ class E2E:
         y = ops.conv(x, self.cnn)                                        # (1, 3, T, 128)
         feat = y[0].permute(0, 2, 1).reshape(1, -1, T)                   # (1, 384, T): row c*128 + f
         gi = ops.conv(feat.contiguous(), self.gru_in)                    # (1, 6*hidden, T)
-        hseq = ops.gru_bidir(gi[0], self.whh_t, self.bhh, self.hidden)   # (2*hidden, T)
+        hseq = ops.gru_bidir(gi[0], self.whh_t, self.bhh, self.hidden, two_workgroups)   # (2*hidden, T)
         sal = ops.conv(hseq.unsqueeze(0), self.fc, act=ops.ACT_SIGMOID)  # (1, 360, T)
         return sal[0].t().contiguous().unsqueeze(0)                      # (1, T, 360)
 
@@ -173,10 +173,10 @@ class RMVPE:
         cents_mapping = 20 * np.arange(360) + 1997.3794084376191
         self.cents_mapping = np.pad(cents_mapping, (4, 4))
 
-    def mel2hidden(self, mel):
+    def mel2hidden(self, mel, two_workgroups=None):
         n_frames = mel.shape[-1]
         mel = F.pad(mel, (0, 32 * ((n_frames - 1) // 32 + 1) - n_frames), mode="reflect")  # frame re-indexing only
-        hidden = self.model(mel)
+        hidden = self.model(mel, two_workgroups)
         return hidden[:, :n_frames]
 
     def _decode_device(self, hidden, thred):
@@ -186,24 +186,26 @@ class RMVPE:
     def decode(self, hidden, thred=0.03):
         """hidden: (T, 360) numpy or tensor -> f0 float64 numpy (src/rmvpe.py:359-364)."""
         h = torch.as_tensor(hidden).to(self.device)
-        out = self._decode_device(h, thred)[1].cpu().numpy()
-        ops.gru_check_pending()
-        return out
+        return self._decode_device(h, thred)[1].cpu().numpy()
 
     def to_local_average_cents(self, salience, thred=0.05):
         s = torch.as_tensor(salience).to(self.device)
         return self._decode_device(s, thred)[0].cpu().numpy()
 
-    def infer_from_audio_device(self, audio, thred=0.03):
-        """infer_from_audio without the final device->host copy: everything is queued on the current stream."""
+    def infer_from_audio_device(self, audio, thred=0.03, two_workgroups=None):
+        """infer_from_audio without the final device->host copy: everything is queued on the current stream.  The caller
+        must consult ops.gru_timed_out() once the stream has drained and, if set, call again with two_workgroups=False."""
         if not torch.is_tensor(audio):
             audio = torch.from_numpy(np.asarray(audio))
         audio = audio.float().to(self.device).unsqueeze(0)
         mel = self.mel_extractor(audio, center=True)
-        hidden = self.mel2hidden(mel)
+        hidden = self.mel2hidden(mel, two_workgroups)
         return self._decode_device(hidden[0], thred)[1]
 
     def infer_from_audio(self, audio, thred=0.03):
         f0 = self.infer_from_audio_device(audio, thred).cpu().numpy()
-        ops.gru_check_pending()
+        if ops.gru_timed_out():
+            # the partner workgroups of the two-workgroup recurrence were not co-resident in time (busy / shared GPU):
+            # recompute on the single-workgroup kernel instead of failing the conversion
+            f0 = self.infer_from_audio_device(audio, thred, two_workgroups=False).cpu().numpy()
         return f0

@@ -294,8 +294,10 @@ class VC(object):
             tf1 = ttime()
             side.synchronize()
             main.wait_stream(side)
-            pitch, pitchf = run_f0(f0_dev.cpu().numpy())
-            ops.gru_check_pending()
+            f0_host = f0_dev.cpu().numpy()
+            if ops.gru_timed_out():  # two-workgroup GRU starved of its partner under the HuBERT load: single-workgroup rerun
+                f0_host = self._rmvpe().infer_from_audio_device(pad_dev, thred=0.03, two_workgroups=False).cpu().numpy()
+            pitch, pitchf = run_f0(f0_host)
             del f0_dev
             t2 = ttime()
             f0_wait = t2 - tf1

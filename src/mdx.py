@@ -1,5 +1,5 @@
 """Drop-in shadow of the reference's src/mdx.py: put this directory ahead of the reference's src/ on sys.path
-(or use src/run_main.py) and main.py's imports resolve to the MI355X implementation."""
+(or launch through src/run_main.py) and main.py's imports resolve to the MI355X implementation."""
 import os as _os, sys as _sys
 _sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
 from aicovergen_amd.mdx import *  # noqa: F401,F403

@@ -115,8 +115,10 @@ def make_rmvpe(name, cfg, seconds, seed):
     print(name, hidden.shape, float((f0 > 0).mean()))
 
 
-def make_pipeline(name, seconds, seed):
-    """End to end: the reference's own VC.pipeline (src/vc_infer_pipeline.py) + its synthesizer + its RMVPE, with
+def make_pipeline(name, seconds, seed, full=False, x=(1, 1, 1, 2)):
+    """`full`: the full-size model set (HuBERT-base, RMVPE, 40 kHz v2 synthesizer) -- BASELINE config C1 when
+    `seconds` = 30 and x = main.py's (3, 10, 60, 65) preset; the reference's f0 / coarse bins are stored too.
+    End to end: the reference's own VC.pipeline (src/vc_infer_pipeline.py) + its synthesizer + its RMVPE, with
     the seeded small model set; HuBERT (fairseq, absent) is served by the oracle restatement (itself pinned to
     transformers.HubertModel).  Missing third-party modules are stubbed exactly as SURVEY 8(c) describes."""
     import types
@@ -140,15 +142,17 @@ def make_pipeline(name, seconds, seed):
     import rmvpe as ref_rmvpe
     import vc_infer_pipeline as ref_vc
     from infer_pack.models import SynthesizerTrnMs768NSFsid
-    nets = weights.small_model_set(seed)
+    nets = weights.full_model_set(seed) if full else weights.small_model_set(seed)
     cfg = nets["synth_cfg"]
     tgt_sr = cfg[-1]
 
     class Cfg:
-        x_pad, x_query, x_center, x_max, is_half, device = 1, 1, 1, 2, False, "cpu"
+        x_pad, x_query, x_center, x_max = x
+        is_half, device = False, "cpu"
 
     vc = ref_vc.VC(tgt_sr, Cfg())
-    e2e = ref_rmvpe.E2E(1, 1, (2, 2), 5, 1, 1, 2)
+    rc = weights.RMVPE_FULL if full else weights.RMVPE_TINY
+    e2e = ref_rmvpe.E2E(rc["n_blocks"], 1, (2, 2), rc["en_de_layers"], rc["inter_layers"], 1, rc["en_out_channels"])
     e2e.load_state_dict(nets["rmvpe_sd"])
     e2e.eval()
     r = ref_rmvpe.RMVPE.__new__(ref_rmvpe.RMVPE)
@@ -178,17 +182,37 @@ def make_pipeline(name, seconds, seed):
         return nz if which == 0 else ns.unsqueeze(-1)
 
     audio = vocal_like(seconds, 16000, seed + 5)
+    f0_seen = {}
+    orig_get_f0 = vc.get_f0
+
+    def spy_get_f0(*a, **k):
+        coarse, f0 = orig_get_f0(*a, **k)
+        f0_seen["coarse"], f0_seen["f0"] = np.asarray(coarse).copy(), np.asarray(f0).copy()
+        return coarse, f0
+
+    vc.get_f0 = spy_get_f0
     torch.randn_like = fake_randn_like
+    import time
+    t0 = time.time()
     try:
         out = vc.pipeline(Hub(), net_g, 0, audio, "x.wav", [0, 0, 0], 0, "rmvpe", "", 0.5, 1, 3, tgt_sr, 0, 0.25, "v2", 0.33, 128)
     finally:
         torch.randn_like = orig
-    np.savez_compressed(os.path.join(HERE, name + ".npz"), seed=np.array([seed]), seconds=np.array([seconds]), audio=out)
-    print(name, out.shape, out.dtype, int(np.abs(out).max()))
+    extra = {}
+    if full:
+        extra = dict(coarse=f0_seen["coarse"].astype(np.int16), f0=f0_seen["f0"].astype(np.float64), x=np.array(x),
+                     ref_cpu_seconds=np.array([time.time() - t0]), ref_threads=np.array([torch.get_num_threads()]))
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), seed=np.array([seed]), seconds=np.array([seconds]), audio=out, **extra)
+    print(name, out.shape, out.dtype, int(np.abs(out).max()), "%.1f s" % (time.time() - t0))
 
 
 if __name__ == "__main__":
     from oracle import weights
+    if len(sys.argv) > 1 and sys.argv[1] == "c1":
+        # BASELINE config C1: 30 s mono 16 kHz through the reference's own VC.pipeline on the CPU, full-size networks,
+        # main.py's chunk preset (one 576 000-sample padded chunk)
+        make_pipeline("pipeline_c1_30s", 30.0, 1234, full=True, x=(3, 10, 60, 65))
+        sys.exit(0)
     make_synth("synth_tiny_T24", weights.SYNTH_CFG_TINY, 24, 1234)
     make_synth("synth_40k_T16", weights.SYNTH_CFG_40K_V2, 16, 1234)
     make_synth("synth_tiny_v1_T24", weights.SYNTH_CFG_TINY, 24, 1234, variant="256f0")

@@ -1,0 +1,181 @@
+"""Parity at the sizes bench.py times: different sizes select different conv tiles / K splits, the
+split-attention merge path, the 16-window MDX batches and the two-workgroup GRU over 24 608 steps.
+
+  * BASELINE config C1: 30 s S16 through VC.pipeline with full-size networks and main.py's (3,10,60,65) preset against the
+    int16 output of the REFERENCE's own VC.pipeline (tests/golden/pipeline_c1_30s.npz, made by tests/golden/make_golden.py c1
+    from /root/reference/src): one 576 000-sample chunk.
+  * one 66 s chunk (T_h = 3300 HuBERT frames, synthesizer T = 6600 -> 2.64 M samples) against the oracle on the host CPU;
+  * whole-track RMVPE on 240 s (24 608 frames) against the oracle, disagreeing frames listed with their salience margins;
+  * a 16-window MDX batch (8 windows x {+x, -x}) at 3072/256/7680 against the oracle per window, and the window counts of a
+    4-minute track.
+All `-m gpu`: the oracle side needs minutes of host CPU even on the GPU box.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_rms
+from oracle import hubert as ohub
+from oracle import mdxnet
+from oracle import pipeline as opipe
+from oracle import rmvpe as orm
+from oracle import synth as osynth
+from synthetic import weights
+from synthetic.inputs import song_like, synth_inputs, vocal_like
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _hip():
+    import conftest
+    conftest._bind("hip")
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    yield
+    torch.cuda.synchronize()
+
+
+def _margins(sal, frames):
+    """top-1 minus top-2 salience of the given frames."""
+    top2 = np.sort(sal[frames], axis=1)[:, -2:]
+    return top2[:, 1] - top2[:, 0]
+
+
+def test_c1_pipeline_vs_reference_golden():
+    """BASELINE C1.  Waveform bar: relative RMS <= 1e-3 on the int16 output; reported: <= 1 LSB rate.
+    f0: every frame whose coarse bin differs from the reference's is listed with its f0 distance and salience margin;
+    the bar is <= 0.2 % of frames, each within one bin (a cents value that rounds across a bin edge)."""
+    from test_pipeline import build, noise_fn_for
+    gold = np.load(os.path.join(GOLD, "pipeline_c1_30s.npz"))
+    seed, x = int(gold["seed"][0]), tuple(int(v) for v in gold["x"])
+    nets = weights.full_model_set(seed)
+    audio = vocal_like(float(gold["seconds"][0]), 16000, seed + 5)
+    import conftest
+    dev = conftest.Dev("hip")
+    vc, hub, net_g, tgt_sr = build(dev, nets, x)
+    times = [0, 0, 0]
+    out = vc.pipeline(hub, net_g, 0, audio, "x.wav", times, 0, "rmvpe", "", 0.5, 1, 3, tgt_sr, 0, 0.25, "v2", 0.33, 128,
+                      noise_fn=noise_fn_for(nets))
+    ref = gold["audio"]
+    assert out.dtype == np.int16 and out.shape == ref.shape == (1199200,)
+    diff = np.abs(out.astype(np.int32) - ref.astype(np.int32))
+    rel = np.sqrt(np.sum(diff.astype(np.float64) ** 2) / np.sum(ref.astype(np.float64) ** 2))
+    print("C1 vs reference: rel rms %.3e, max |diff| %d of peak %d, <= 1 LSB on %.4f, exact on %.4f"
+          % (rel, diff.max(), np.abs(ref).max(), (diff <= 1).mean(), (diff == 0).mean()))
+    assert rel < 1e-3
+    assert (diff <= 1).mean() > 0.9
+    # f0 bins against the reference's own get_f0 output
+    _, audio_pad, opt_ts, p_len = vc.plan(audio)
+    assert opt_ts == []                                             # 30 s < x_max: a single chunk
+    assert audio_pad.shape[0] == 576000
+    coarse, f0 = vc.get_f0("x.wav", audio_pad, p_len, 0, "rmvpe", 3, 128)
+    n = min(len(coarse), len(gold["coarse"]))
+    bad = np.nonzero(coarse[:n] != gold["coarse"][:n])[0]
+    r = vc.model_rmvpe
+    mel = r.mel_extractor(torch.from_numpy(audio_pad).float()[None].cuda(), center=True)
+    sal = r.mel2hidden(mel)[0].cpu().numpy()
+    for t, m in zip(bad, _margins(sal, bad)):
+        print("  frame %d: bin %d vs reference %d, f0 %.4f vs %.4f Hz, salience top1-top2 %.3e"
+              % (t, coarse[t], gold["coarse"][t], f0[t], gold["f0"][t], m))
+    print("C1 coarse-bin agreement %.5f (%d of %d frames differ)" % (1 - len(bad) / n, len(bad), n))
+    assert len(bad) <= 0.002 * n
+    assert np.all(np.abs(coarse[:n][bad].astype(int) - gold["coarse"][:n][bad].astype(int)) <= 1)
+    voiced = (f0[:n] > 0) & (gold["f0"][:n] > 0)
+    assert np.array_equal(f0[:n] > 0, gold["f0"][:n] > 0) or (np.sum((f0[:n] > 0) != (gold["f0"][:n] > 0)) <= 0.002 * n)
+    assert np.max(np.abs(f0[:n][voiced] / gold["f0"][:n][voiced] - 1)) < 1e-3
+
+
+def test_66s_chunk_hubert_and_synth_vs_oracle():
+    """The chunk size of the (3,10,60,65) preset: 1 056 160 samples -> T_h = 3300 (4-way split attention, 64x64 tiles on the
+    QKV/FFN GEMMs), synthesizer T = 6600 -> 2 640 000 output samples (vocoder tiles of the bench)."""
+    from aicovergen_amd.hubert import HubertModel
+    from aicovergen_amd.infer_pack.models import SynthesizerTrnMs768NSFsid
+    n = 1056160
+    wav = torch.from_numpy(vocal_like(n / 16000.0 + 0.01, 16000, seed=31)[:n]).unsqueeze(0)
+    cfg = weights.HUBERT_BASE
+    sd = weights.hubert_state_dict(cfg, 1234)
+    m = HubertModel(sd, cfg).to("cuda:0")
+    y, _ = m.extract_features(source=wav, padding_mask=None, output_layer=12)
+    assert y.shape == (1, 3300, 768)
+    with torch.no_grad():
+        ref = ohub.extract_features(sd, cfg, wav, 12)
+    e = rel_rms(y, ref)
+    print("HuBERT-base T_h=3300: rel rms %.3e" % e)
+    assert e < 1e-4
+    del m, y, ref
+    scfg, T = weights.SYNTH_CFG_40K_V2, 6600
+    ssd = weights.synth_state_dict(scfg, 1236)
+    net = SynthesizerTrnMs768NSFsid(*scfg, is_half=False)
+    del net.enc_q
+    net.load_state_dict(ssd, strict=False)
+    net.eval().to("cuda:0")
+    phone, pitch, f0, nz, ns = synth_inputs(scfg, T, 77)
+    o, _, (z, z_p, m_p, logs_p) = net.infer(phone, torch.tensor([T]), pitch, f0, torch.tensor([3]), noise_z=nz, noise_src=ns)
+    assert o.shape == (1, 1, 2640000)
+    with torch.no_grad():
+        ro, (rz, rzp, rmp, rlp) = osynth.synth_infer(ssd, scfg, phone, pitch, f0, torch.tensor([3]), nz, ns)
+    e_mp, e_z, e_o = rel_rms(m_p, rmp), rel_rms(z, rz), rel_rms(o, ro)
+    print("synthesizer T=6600: rel rms m_p %.3e, z %.3e, audio %.3e" % (e_mp, e_z, e_o))
+    assert e_mp < 1e-4 and e_z < 1e-4 and e_o < 1e-3
+
+
+def test_240s_rmvpe_vs_oracle():
+    """Whole-track f0 of a 4-minute input: 24 001 frames padded to 24 032, the two-workgroup GRU over every step."""
+    from aicovergen_amd.rmvpe import RMVPE
+    from aicovergen_amd import ops
+    sd = weights.rmvpe_state_dict(weights.RMVPE_FULL, 1235)
+    r = RMVPE(None, False, "cuda:0", state_dict=sd)
+    audio = vocal_like(240.0, 16000, seed=1234)
+    audio = np.pad(audio, (48000, 48000), mode="reflect")          # what pipeline() hands get_f0 (t_pad = 3 s)
+    f0 = r.infer_from_audio(audio, 0.03)
+    assert not ops.gru_timed_out()
+    mel = r.mel_extractor(torch.from_numpy(audio)[None].cuda(), center=True)
+    hid = r.mel2hidden(mel)[0].cpu().numpy()
+    of0, ohid = orm.infer_from_audio(sd, audio, 0.03)
+    assert hid.shape == ohid.shape and hid.shape[0] == 24601
+    print("RMVPE 246 s: salience max |diff| %.3e" % np.abs(hid - ohid).max())
+    assert np.abs(hid - ohid).max() < 1e-3
+    bad = np.nonzero(hid.argmax(1) != ohid.argmax(1))[0]
+    for t, m in zip(bad[:50], _margins(ohid, bad[:50])):
+        print("  frame %d: argmax %d vs oracle %d, oracle top1-top2 margin %.3e" % (t, hid[t].argmax(), ohid[t].argmax(), m))
+    print("salience argmax agreement %.5f (%d frames differ)" % (1 - len(bad) / len(hid), len(bad)))
+    assert len(bad) <= 0.002 * len(hid)
+    if len(bad):
+        assert _margins(ohid, bad).max() < 1e-3                    # only near-ties may flip
+    ok = np.ones(len(hid), bool)
+    ok[bad] = False
+    assert np.array_equal((f0 > 0)[ok], (of0 > 0)[ok]) or np.sum((f0 > 0)[ok] != (of0 > 0)[ok]) <= 5
+    v = ok & (f0 > 0) & (of0 > 0)
+    assert np.max(np.abs(f0[v] / of0[v] - 1)) < 1e-3
+
+
+def test_mdx_16_window_batch_vs_oracle_and_window_counts():
+    """The bench's MDX launches: 8 windows x {+x, -x} = 16 images through stft -> U-Net -> istft in one batch; three of the
+    eight windows are checked against the oracle (one U-Net forward costs the host ~0.8 TFLOP).  Window counts of a
+    4-minute track: 2 segments of 5 336 100 samples -> 22 windows each, pad 239 580."""
+    from aicovergen_amd.mdx import MDX, MDXModel
+    cfg = weights.MDX_VOC_FT
+    sd = weights.mdx_state_dict(cfg, 1234)
+    model = MDXModel("cuda:0", cfg["dim_f"], cfg["dim_t"], cfg["n_fft"])
+    sess = MDX(None, model, state_dict=sd)
+    n = 240 * 44100
+    segs = MDX.segment(np.zeros((2, n), np.float32), False, n // 2)
+    assert [s.shape[1] for s in segs] == [5336100, 5336100]
+    trim, gen, pad = sess._geometry(5336100)
+    assert (gen, pad, (5336100 + pad) // gen) == (253440, 239580, 22)
+    assert sess.WINDOW_BATCH == 8
+    wave = song_like(8 * gen / 44100.0 + 0.5, 44100, seed=5)[:, :8 * gen - 1000]
+    mix, pad8, trim = sess.pad_wave(wave)
+    assert mix.shape == (8, 2, model.chunk_size)
+    mw = torch.cat([mix, -mix], 0)
+    with torch.no_grad():
+        got = model.istft_tf(sess.net.forward_tf(model.stft_tf(mw)))
+        for w in (0, 5, 15):
+            x = mw[w:w + 1].cpu()
+            ref = mdxnet.istft(mdxnet.unet(sd, cfg, mdxnet.stft(x, cfg["n_fft"], 1024, cfg["dim_f"])), cfg["n_fft"], 1024)
+            e = rel_rms(got[w:w + 1], ref)
+            print("MDX window %d of the 16-image batch: rel rms %.3e" % (w, e))
+            assert e < 1e-4

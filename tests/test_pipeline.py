@@ -142,6 +142,11 @@ def test_device_post_processing_matches_oracle(dev):
     r2 = ops.frame_rms(dev.t(torch.from_numpy(b)), 40000, 20000)
     assert np.allclose(r1.cpu().numpy(), opipe.rms_frames(a, 16000, 8000)[0], rtol=1e-12)
     assert np.allclose(r2.cpu().numpy(), opipe.rms_frames(b, 40000, 20000)[0], rtol=1e-6)
+    # clips of <= 0.5 s: the reflect padding is longer than the signal (numpy reflects repeatedly, librosa.feature.rms accepts it)
+    for n in (1, 2, 37, 3000, 8000, 8001):
+        c = rng.standard_normal(n)
+        assert np.allclose(ops.frame_rms(dev.t(torch.from_numpy(c)), 16000, 8000).cpu().numpy(),
+                           opipe.rms_frames(c, 16000, 8000)[0], rtol=1e-12), n
     want = opipe.change_rms(a, 16000, b.copy(), 40000, 0.25)
     d = dev.t(torch.from_numpy(b.copy()))
     ops.rms_mix_(d, r1, r2, 0.25)
