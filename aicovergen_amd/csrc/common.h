@@ -55,7 +55,12 @@ __device__ __forceinline__ void lds_barrier() {
 #ifdef AICG_EMULATED
     __builtin_amdgcn_s_barrier();
 #else
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // The wait goes through the builtin, not the asm string: the compiler's counter model then knows that no scalar load is
+    // pending after a barrier.  With an opaque wait a kernel-argument s_load hoisted above the K loop stayed "pending" for the
+    // whole loop in that model, and with two event types on lgkmcnt every fragment wait in the MFMA loop degraded to
+    // lgkmcnt(0) -- the reads of k-step s+1, issued just before, were drained ahead of the MFMAs of step s (r2 ISA audit).
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0); vmcnt / expcnt untouched (gfx9 encoding: [11:8] lgkm, [3:0]+[15:14] vm, [6:4] exp)
+    asm volatile("s_barrier" ::: "memory");
 #endif
 }
 
