@@ -64,6 +64,45 @@ __device__ __forceinline__ void lds_barrier() {
 #endif
 }
 
+// Buffer-resource loads: SGPR base + one 32-bit VGPR byte offset per load (a 64-bit global_load address costs two VGPRs and
+// a carry chain per load), and the hardware range check returns 0 for offsets >= num_records -- zero padding and absent
+// channels need no mask, no select and no exec juggling: invalid slots simply carry the offset kBufOob.
+#ifdef AICG_EMULATED
+struct BufRsrc { const char* base; unsigned num_records; };
+__device__ __forceinline__ BufRsrc make_buf(const void* base, unsigned num_bytes) { return BufRsrc{(const char*)base, num_bytes}; }
+__device__ __forceinline__ float buf_load_f32(const BufRsrc& r, unsigned voff) {
+    if ((unsigned long)voff + 4 > r.num_records) return 0.f;
+    return *reinterpret_cast<const float*>(r.base + voff);
+}
+__device__ __forceinline__ float4 buf_load_f32x4(const BufRsrc& r, unsigned voff) {
+    if ((unsigned long)voff + 16 > r.num_records) return make_float4(0.f, 0.f, 0.f, 0.f);
+    return *reinterpret_cast<const float4*>(r.base + voff);
+}
+#else
+// The raw-buffer intrinsics are bound by name (the clang builtin __builtin_amdgcn_raw_buffer_load_b128 of ROCm 7.2 lowers to
+// a 32-bit load and splats it); the resource is the classic 4-dword descriptor {base[47:0], stride 0, num_records, flags}.
+typedef int buf_i32x4 __attribute__((ext_vector_type(4)));
+typedef float buf_f32x4 __attribute__((ext_vector_type(4)));
+__device__ float llvm_amdgcn_raw_buffer_load_f32(buf_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ buf_f32x4 llvm_amdgcn_raw_buffer_load_v4f32(buf_i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+struct BufRsrc { buf_i32x4 d; };
+__device__ __forceinline__ BufRsrc make_buf(const void* base, unsigned num_bytes) {
+    const unsigned long a = (unsigned long)base;
+    BufRsrc r;
+    r.d.x = (int)(unsigned)(a & 0xffffffffu);
+    r.d.y = (int)(unsigned)((a >> 32) & 0xffffu);  // stride 0, no swizzle: raw buffer
+    r.d.z = (int)num_bytes;
+    r.d.w = 0x00020000;                            // 32-bit data format, range checking on raw offsets
+    return r;
+}
+__device__ __forceinline__ float buf_load_f32(const BufRsrc& r, unsigned voff) { return llvm_amdgcn_raw_buffer_load_f32(r.d, (int)voff, 0, 0); }
+__device__ __forceinline__ float4 buf_load_f32x4(const BufRsrc& r, unsigned voff) {
+    const buf_f32x4 v = llvm_amdgcn_raw_buffer_load_v4f32(r.d, (int)voff, 0, 0);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+#endif
+static constexpr unsigned kBufOob = 0x80000000u;  // any byte offset >= 2^31 is out of range for the buffers made here
+
 // block->XCD aware remap (guide T1, bijective form): consecutive logical ids share an XCD's L2.
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
     const unsigned nx = 8;

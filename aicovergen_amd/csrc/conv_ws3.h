@@ -1,0 +1,290 @@
+// Wave-specialised implicit-GEMM convolution, third form: 16-byte MFMA fragments.
+//
+// r2 micro-probe (tools/probes/mfma_loop_probe.hip, one consumer wave per SIMD, v_mfma_f32_32x32x2_f32):
+//     MFMAs on constant operands                              192 cycles per k-step (TM = 3: the issue floor)
+//     + ds_read_b32 fragments, results unused                 192
+//     + the MFMAs consume them (the conv_ws_kernel loop)      256   (prefetch distance 1 or 2: same)
+//     + fragments of four k-steps per ds_read_b128            204
+// Every hand-over of LDS-loaded registers to the matrix pipe costs the wave one bubble of ~50-64 cycles, whatever the prefetch
+// distance; with one hand-over per k-step that is a quarter of a 3-MFMA k-step and a third of a 2-MFMA one.  Here both
+// operands are laid out in LDS so that ONE ds_read_b128 per fragment feeds FOUR k-steps:
+//
+//   v_mfma_f32_32x32x2_f32, k-step s: lane (l31, half) supplies A[m = l31][k = 2 s + half] and B[k = 2 s + half][n = l31].
+//   K is cut into groups of 8 rows; lane `half` needs rows {half, 2 + half, 4 + half, 6 + half} of a group for its four k-steps:
+//       weights  [group][parity][m][4]      element j of the float4 = row 8 group + 2 j + parity     (m contiguous: conflict-free)
+//       patch    [group][parity][pos][4]    channel 8 group + 2 j + parity at patch position pos     (a tap = a shift of pos)
+//   The packed weight image in HBM has the same order ([tap][Cin_pad / 8][2][Mpad][4], appended to the classic image), so a weight
+//   stage is still a few coalesced float4 copies; a producer thread gathers the 4 channels of a patch quad with 4 coalesced dword
+//   loads and writes one ds_write_b128.
+//
+// Everything else (producer / consumer roles, stage hand-over through one LDS-only barrier, buffer-resource loads with
+// range-checked zero padding, tile walk, epilogue) is conv_ws_kernel's.  Layers with fewer than 8 input channels per group and
+// the 160-row tile (5 x 16 accumulators + two sets of 16-byte fragments do not fit 128 registers) stay on conv_ws_kernel.
+#pragma once
+#include "conv_kernels.h"
+
+namespace aicg {
+
+template <int BM, int KS>
+struct Ws3Geom {
+    static constexpr int PNT = 256;
+    static constexpr int WR = (KS * BM / 4 + PNT - 1) / PNT;      // float4 weight copies per producer thread per stage
+    // + 8 slack rows: the consumers' last (discarded) fragment prefetch of a stage reads one k-group past it
+    static constexpr int WS_ELEMS = ((KS + 8) * BM > WR * PNT * 4) ? (KS + 8) * BM : WR * PNT * 4;
+};
+
+// Producer role: 256 threads stage every K stage of one output tile.  XQ = patch quads (float4 of 4 channels) per thread.
+template <int BM, int XQ, int KS, bool BOOST>
+__device__ __forceinline__ void ws3_produce(const ConvArgs& p, float* xs0, float* ws0, int ptid, int n, int g, int h0, int w0, int m_base,
+                                            int nstages) {
+    constexpr int PNT = 256;
+    constexpr int WR = Ws3Geom<BM, KS>::WR;
+    constexpr int WS_ELEMS = Ws3Geom<BM, KS>::WS_ELEMS;
+    constexpr int XS_ELEMS = XQ * PNT * 4;
+    const float* xg = p.x + (long)n * p.x_sn + (long)g * p.Cin_g * p.x_sc;
+    const float* wg = p.w3 + (long)g * p.w_group_stride + (long)m_base * 4;
+    if (BOOST) __builtin_amdgcn_s_setprio(2);
+    // byte offsets relative to the chunk / stage base, kBufOob for slots that must read as zero (see ws_produce)
+    unsigned poff[XQ], woff[WR];
+    const int quads_per_chunk = (p.BKC >> 2) * p.CHS;   // (group, parity) planes x positions
+    {
+        const int hin0 = h0 * p.sh - p.ph, win0 = w0 * p.sw - p.pw;
+#pragma unroll
+        for (int e = 0; e < XQ; ++e) {
+            const int idx = ptid + e * PNT;
+            const int plane = (int)__umulhi((unsigned)idx, p.div_chs);   // = 2 * group + parity
+            const int rem = idx - plane * p.CHS;
+            const int r = (int)__umulhi((unsigned)rem, p.div_twp);
+            const int col = rem - r * p.TWp;
+            const int hin = hin0 + r, win = win0 + col;
+            const bool ok = idx < quads_per_chunk && col < p.TW_in && hin >= 0 && hin < p.H && win >= 0 && win < p.W;
+            const int ci = 8 * (plane >> 1) + (plane & 1);               // channel of element j = 0; element j is 2 j channels on
+            poff[e] = ok ? 4u * (unsigned)(ci * p.x_sc + hin * p.x_sh + win) : kBufOob;
+        }
+        const int slabs_per_tap = p.BKC >> 2;            // (group, parity) slabs of BM float4 per tap of a stage
+        const int slab_tap_stride = (p.Cin_pad >> 2);    // slabs per tap in the packed image
+#pragma unroll
+        for (int e = 0; e < WR; ++e) {
+            const int idx4 = ptid + e * PNT;
+            const int slab = idx4 / BM;                  // stage-local slab: (tap-in-stage, group, parity)
+            const int m = idx4 - slab * BM;
+            const int tt = slab / slabs_per_tap, sl = slab - tt * slabs_per_tap;
+            const bool ok = m_base + m < p.Mpad && slab < KS / 4;
+            woff[e] = ok ? 16u * (unsigned)((tt * slab_tap_stride + sl) * p.Mpad + m) : kBufOob;
+        }
+    }
+    const unsigned ch2 = 8u * (unsigned)p.x_sc;          // byte distance of two channels: element j -> j + 1 of a quad
+    auto load = [&](int c, int tap0, float4 (&wv)[WR], float4 (&xv)[XQ]) {
+        // stage base: slab ((tap0 * Cin_pad / 8 + c * BKC / 8) * 2) of this group's v3 image
+        const long wbase = ((long)tap0 * (p.Cin_pad >> 2) + (long)c * (p.BKC >> 2)) * p.Mpad * 4;
+        const BufRsrc wb = make_buf(wg + wbase, (unsigned)lmin(((long)p.taps * p.Cin_pad * p.Mpad - wbase - (long)m_base * 4) * 4, 0x7fffffffL));
+#pragma unroll
+        for (int e = 0; e < WR; ++e) wv[e] = buf_load_f32x4(wb, woff[e]);
+        if (tap0 == 0) {  // a new channel chunk: its input patch (halo included)
+            const long left = (long)(p.Cin_g - c * p.BKC) * p.x_sc * 4;  // bytes up to the end of this group's channels
+            const BufRsrc xb = make_buf(xg + (long)c * p.BKC * p.x_sc, (unsigned)lmin(left, 0x7fffffffL));
+#pragma unroll
+            for (int e = 0; e < XQ; ++e) {
+                xv[e].x = buf_load_f32(xb, poff[e]);
+                xv[e].y = buf_load_f32(xb, poff[e] + ch2);
+                xv[e].z = buf_load_f32(xb, poff[e] + 2u * ch2);
+                xv[e].w = buf_load_f32(xb, poff[e] + 3u * ch2);
+            }
+        }
+    };
+    auto commit = [&](int st, int c, int tap0, float4 (&wv)[WR], float4 (&xv)[XQ]) {
+        if (tap0 == 0) {
+            float* xs = xs0 + (c & 1) * XS_ELEMS + ptid * 4;
+            if (p.pre_act == AICG_ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < XQ; ++e) *reinterpret_cast<float4*>(xs + e * PNT * 4) = xv[e];
+            } else if (p.pre_act == AICG_ACT_LRELU) {
+                const float sl = p.pre_slope;
+#pragma unroll
+                for (int e = 0; e < XQ; ++e) {
+                    float4 v = xv[e];
+                    v.x = v.x > 0.f ? v.x : v.x * sl; v.y = v.y > 0.f ? v.y : v.y * sl;
+                    v.z = v.z > 0.f ? v.z : v.z * sl; v.w = v.w > 0.f ? v.w : v.w * sl;
+                    *reinterpret_cast<float4*>(xs + e * PNT * 4) = v;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < XQ; ++e) {
+                    float4 v = xv[e];
+                    v.x = apply_act(v.x, p.pre_act, p.pre_slope); v.y = apply_act(v.y, p.pre_act, p.pre_slope);
+                    v.z = apply_act(v.z, p.pre_act, p.pre_slope); v.w = apply_act(v.w, p.pre_act, p.pre_slope);
+                    *reinterpret_cast<float4*>(xs + e * PNT * 4) = v;
+                }
+            }
+        }
+        float* ws = ws0 + (st & 1) * WS_ELEMS + ptid * 4;
+#pragma unroll
+        for (int e = 0; e < WR; ++e) *reinterpret_cast<float4*>(ws + e * PNT * 4) = wv[e];
+    };
+    auto next = [&](int& c, int& tap0) {
+        tap0 += p.TT;
+        if (tap0 >= p.taps) { tap0 = 0; ++c; }
+    };
+    float4 wv[WR];
+    float4 xv[XQ];
+    int c = 0, t = 0;
+    load(c, t, wv, xv);
+    for (int st = 0; st < nstages; ++st) {
+        commit(st, c, t, wv, xv);
+        next(c, t);
+        if (st + 1 < nstages) load(c, t, wv, xv);
+        lds_barrier();  // stage st published (and the consumers are done with stage st - 1)
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int XQ, int KS, bool GEN>
+__global__ void __launch_bounds__(64 * (WM * WN + 4), (WM * WN == 4 ? 4 : 3)) conv_ws3_kernel(ConvArgs p) {
+    constexpr int CW = WM * WN, CNT = 64 * CW, PNT = 256;
+    constexpr int TM = BM / (32 * WM);
+    constexpr int TN = BN / (32 * WN);
+    constexpr int WS_ELEMS = Ws3Geom<BM, KS>::WS_ELEMS;
+    constexpr int XS_ELEMS = XQ * PNT * 4;
+    HIP_DYNAMIC_SHARED(float, smem)
+    float* const xs0 = smem;
+    float* const ws0 = smem + 2 * XS_ELEMS;
+
+    const int tid = threadIdx.x;
+    const int bx = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int tw_i = bx % p.tiles_w;
+    const int th_i = (bx / p.tiles_w) % p.tiles_h;
+    const int n = bx / (p.tiles_w * p.tiles_h);
+    const int w0 = tw_i * p.TW, h0 = th_i * p.TH;
+    const int m_base = blockIdx.y * BM;
+    const int g = blockIdx.z;
+    const int stages_per_chunk = (p.taps + p.TT - 1) / p.TT;
+    const int nstages = p.nchunk * stages_per_chunk;
+
+    if (tid >= CNT) {
+        ws3_produce<BM, XQ, KS, CW == 8>(p, xs0, ws0, tid - CNT, n, g, h0, w0, m_base, nstages);
+        return;
+    }
+
+    // ================= consumers =================
+    const int lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int wm = wave / WN, wn = wave % WN;
+    // float4 index of this lane's B fragment inside a (group, parity) plane pair, per column tile
+    int boff[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nl = wn * (TN * 32) + j * 32 + l31;
+        const int jh = nl >> p.TWlog2, jw = nl & (p.TW - 1);
+        boff[j] = jh * p.sh * p.TWp + jw * p.sw + half * p.CHS;
+    }
+    f32x16 acc[TM][TN];
+    ws_init_acc32<TM, TN>(p, acc, g, m_base + wm * (TM * 32), half);
+    const int a_off = wm * (TM * 32) + l31 + half * BM;   // float4 index inside a slab pair
+    {
+        int c = 0, tap0 = 0;
+        const int gpt = p.BKC >> 3;   // k-groups per tap
+        for (int st = 0; st < nstages; ++st) {
+            lds_barrier();  // stage st is in LDS
+            const float4* xs = reinterpret_cast<const float4*>(xs0 + (c & 1) * XS_ELEMS);
+            const float4* wt = reinterpret_cast<const float4*>(ws0 + (st & 1) * WS_ELEMS) + a_off;
+            const int nt = imin(p.TT, p.taps - tap0);
+            const int ngroups = nt * gpt;   // k-groups (8 rows = 4 k-steps) of this stage
+            // patch float4 offset of the (tap, group) being fetched, advanced incrementally: + 2 planes per group, then to the next
+            // column tap, then to the next kernel row
+            const int kh0 = tap0 / p.KW;
+            int kw = tap0 - kh0 * p.KW, gg = 0;
+            int xoff = kh0 * p.dh * p.TWp + kw * p.dw;
+            const int step_g = 2 * p.CHS, next_tap = p.dw - gpt * 2 * p.CHS, next_row = p.dh * p.TWp - p.KW * p.dw;
+            float4 a0[TM], b0[TN], a1[TM], b1[TN];
+            auto fetch = [&](float4 (&a)[TM], float4 (&b)[TN], int s) {
+                const float4* xt = xs + xoff;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = wt[s * 2 * BM + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = xt[boff[j]];
+                xoff += step_g;
+                if (++gg == gpt) { gg = 0; xoff += next_tap; if (++kw == p.KW) { kw = 0; xoff += next_row; } }
+            };
+            auto mma = [&](float4 (&a)[TM], float4 (&b)[TN]) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const float av = u == 0 ? a[i].x : u == 1 ? a[i].y : u == 2 ? a[i].z : a[i].w;
+                            const float bv = u == 0 ? b[j].x : u == 1 ? b[j].y : u == 2 ? b[j].z : b[j].w;
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                        }
+            };
+            fetch(a0, b0, 0);
+            int s = 0;
+            for (; s + 2 <= ngroups; s += 2) {
+                fetch(a1, b1, s + 1);
+                mma(a0, b0);
+                fetch(a0, b0, s + 2);  // unconditional: past the last group this reads (never uses) the LDS slack rows
+                mma(a1, b1);
+            }
+            if (s < ngroups) mma(a0, b0);
+            tap0 += p.TT;
+            if (tap0 >= p.taps) { tap0 = 0; ++c; }
+        }
+    }
+    const bool interior = m_base + BM <= p.Cout_g && h0 + p.TH <= p.Ho && w0 + p.TW <= p.Wo;
+    ws_epilogue32<TM, TN, GEN>(p, acc, n, g, m_base + wm * (TM * 32), wn * (TN * 32), h0, w0, l31, half, interior);
+}
+
+// returns 0 launched, < 0 error, 1 the configuration does not fit this form
+template <int BM, int BN, int WM, int WN, int KS>
+static int launch_conv_ws3(ConvArgs& p, hipStream_t stream) {
+    if (p.Cin_g < 8 || !p.w3) return 1;
+    p.TW = choose_tile_width(p, BN);
+    p.TWlog2 = ilog2(p.TW);
+    p.TH = BN / p.TW;
+    p.TH_in = (p.TH - 1) * p.sh + (p.KH - 1) * p.dh + 1;
+    p.TW_in = (p.TW - 1) * p.sw + (p.KW - 1) * p.dw + 1;
+    p.TWp = p.TW_in | 1;
+    p.CHS = p.TH_in * p.TWp;
+    p.tiles_w = idiv_up(p.Wo, p.TW);
+    p.tiles_h = idiv_up(p.Ho, p.TH);
+    p.BKC = 32;
+    while (p.BKC > 8 && (p.BKC * p.CHS > 12 * 256 || p.BKC >= 2 * p.Cin_g)) p.BKC >>= 1;
+    p.BKClog2 = ilog2(p.BKC);
+    {
+        const int cap = imax(1, KS / p.BKC);
+        const int nstg = idiv_up(p.taps, cap);
+        p.TT = idiv_up(p.taps, nstg);
+    }
+    p.nchunk = idiv_up(p.Cin_g, p.BKC);
+    p.xs_total = p.BKC * p.CHS;
+    p.xs_elems = (p.xs_total + 3) & ~3;
+    p.div_chs = div_mul(p.CHS);
+    p.div_twp = div_mul(p.TWp);
+    if (p.xs_total > 12 * 256) return 1;
+    const int xq = idiv_up(p.xs_total / 4, 256) <= 2 ? 2 : 3;
+    const size_t lds = (size_t)(2 * xq * 256 * 4 + 2 * Ws3Geom<BM, KS>::WS_ELEMS) * sizeof(float);
+    // 32-bit byte offsets below kBufOob: a channel chunk (plus the 6 channels a quad reaches past its first) and a group of packed
+    // weights must span < 2^31 bytes
+    const bool off_ok = (long)(p.BKC + 8) * p.x_sc + (long)p.H * p.x_sh < (1L << 29) && (long)p.taps * p.Cin_pad * p.Mpad < (1L << 29);
+    if (lds > 160 * 1024 || !off_ok || (long)p.xs_total * p.CHS >= (1L << 32)) return 1;
+    const long gx = (long)p.N * p.tiles_h * p.tiles_w;
+    if (gx > 2147483647L) return fail(AICG_E_SHAPE, "conv: too many output tiles");
+    dim3 grid((unsigned)gx, (unsigned)idiv_up(p.Cout_g, BM), (unsigned)p.groups);
+    dim3 block(64 * (WM * WN + 4));
+    const bool gen = p.shuffle || p.res_mul;
+    p.stagger = p.stagger_first = 0;
+    auto kern = gen ? (xq == 2 ? conv_ws3_kernel<BM, BN, WM, WN, 2, KS, true> : conv_ws3_kernel<BM, BN, WM, WN, 3, KS, true>)
+                    : (xq == 2 ? conv_ws3_kernel<BM, BN, WM, WN, 2, KS, false> : conv_ws3_kernel<BM, BN, WM, WN, 3, KS, false>);
+    allow_dynamic_lds((const void*)kern, lds);
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
+    return check_launch("conv_ws3_kernel");
+}
+
+// instantiation units (conv_ws3_*.hip)
+int run_ws3_128x128(ConvArgs& p, hipStream_t st);   // 4 consumers x (128 x 32), 32-row stages
+int run_ws3_96x128(ConvArgs& p, hipStream_t st);    // 4 consumers x (96 x 32)
+int run_ws3_64x128(ConvArgs& p, hipStream_t st);    // 4 consumers (2 x 2) x (32 x 64)
+int run_ws3_64x64(ConvArgs& p, hipStream_t st);     // 4 consumers (2 x 2) x (32 x 32)
+int run_ws3_32x256(ConvArgs& p, hipStream_t st);    // 4 consumers x (32 x 64)
+int run_ws3_32x128(ConvArgs& p, hipStream_t st);    // 4 consumers x (32 x 32)
+
+}  // namespace aicg

@@ -143,7 +143,7 @@ class ConvDesc(ctypes.Structure):
                [("pre_act", ctypes.c_int32), ("pre_slope", ctypes.c_float), ("act", ctypes.c_int32),
                 ("act_slope", ctypes.c_float), ("out_scale", ctypes.c_float), ("accumulate", ctypes.c_int32),
                 ("res_before_act", ctypes.c_int32), ("pad_h_end", ctypes.c_int32), ("pad_w_end", ctypes.c_int32),
-                ("shuffle", ctypes.c_int32), ("res_mul", ctypes.c_int32)]
+                ("shuffle", ctypes.c_int32), ("res_mul", ctypes.c_int32), ("packed_v3", ctypes.c_int32)]
 
 
 def conv_bkc(taps):
@@ -151,8 +151,8 @@ def conv_bkc(taps):
 
 
 def pack_conv_weight(w, groups=1):
-    """(Cout, Cin/groups, KH, KW) -> per group [tap][Cin_pad][Mpad] (pure re-layout + zero pad; Cin_pad and Mpad are
-    multiples of 32)."""
+    """(Cout, Cin/groups, KH, KW) -> two images back to back (pure re-layout + zero pad; Cin_pad and Mpad are multiples of
+    32): per group [tap][Cin_pad][Mpad], then per group [tap][Cin_pad/8][2][Mpad][4] (aicg_conv_desc.packed_v3)."""
     w = w.detach().to(torch.float32)
     cout, cin_g, kh, kw = w.shape
     taps = kh * kw
@@ -161,7 +161,10 @@ def pack_conv_weight(w, groups=1):
     mpad = (cout_g + 31) // 32 * 32
     out = torch.zeros((groups, taps, cpad, mpad), dtype=torch.float32, device=w.device)
     out[:, :, :cin_g, :cout_g] = w.reshape(groups, cout_g, cin_g, taps).permute(0, 3, 2, 1)
-    return out.contiguous()
+    # second image for the 16-byte-fragment kernels (csrc/conv_ws3.h): input channel ci = 8 q + 2 j + parity is element j of the
+    # quad at [tap][q][parity][m]
+    v3 = out.reshape(groups, taps, cpad // 8, 4, 2, mpad).permute(0, 1, 2, 4, 5, 3)
+    return torch.cat([out.reshape(-1), v3.reshape(-1)]).contiguous()
 
 
 class PackedConv:
@@ -270,6 +273,7 @@ def conv(x, pc, res=None, out=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NON
     d.res_before_act = 1 if res_before_act else 0
     d.pad_h_end, d.pad_w_end = (-1, -1) if pc.padding_end is None else pc.padding_end
     d.shuffle, d.res_mul = int(shuffle), 1 if res_mul else 0
+    d.packed_v3 = 1
     prof = conv_profile
     if prof is not None and x.is_cuda:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -109,6 +109,10 @@ typedef struct aicg_conv_desc {
                                      y[n][m >> 2][2 ho + ((m >> 1) & 1)][2 wo + (m & 1)]; y (and res) strides describe that
                                      (N, Cout/4, 2 Ho, 2 Wo) tensor, bias has Cout entries */
     int32_t res_mul;              /* nonzero: y = out_scale * (act(acc + bias) * res) -- multiplicative U-Net skip */
+    int32_t packed_v3;            /* nonzero: w_packed holds two images of the weights back to back, each
+                                     groups * KH*KW * Cin_pad * Mpad floats: the classic [tap][Cin_pad][Mpad] one and the
+                                     k8-interleaved [tap][Cin_pad/8][2][Mpad][4] one (element j of a quad = input channel
+                                     8 q + 2 j + parity) that the 16-byte-fragment kernels read */
 } aicg_conv_desc;
 
 int aicg_conv_bkc(int taps);
