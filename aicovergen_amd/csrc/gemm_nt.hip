@@ -6,6 +6,8 @@
 // belongs to, ch = (r / rows_per_ch) % n_ch); v = act(v); v += res[r][o].
 // Both tiles are staged through LDS with an odd row stride, so the strided fragment reads
 // (lane -> row, fixed k) are bank-conflict free.
+#include <type_traits>
+
 #include "common.h"
 
 namespace aicg {
@@ -103,28 +105,50 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmArgs p) {
             mma(a1, b1);
         }
     }
-    // D layout: col (n = o) = lane & 31, row (m = r) = (reg & 3) + 8 * (reg >> 2) + 4 * half
+    // D layout: col (n = o) = lane & 31, row (m = r) = (reg & 3) + 8 * (reg >> 2) + 4 * half.
+    // The per-channel affine (eval BatchNorm2d) is constant over a 32-row MFMA tile when rows_per_ch is a multiple of 32 (the MDX
+    // maps have rows_per_ch = dim_t = 256): one division per tile instead of one per element.
+    const bool ch_per_tile = p.row_scale && (p.rows_per_ch & 31) == 0;
+    auto epilogue = [&](auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int o = o0 + wn * 64 + j * 32 + l31;
-        if (o >= p.O) continue;
-        const float bo = p.bias ? p.bias[o] : 0.f;
+        for (int j = 0; j < 2; ++j) {
+            const int o = o0 + wn * 64 + j * 32 + l31;
+            if (o >= p.O) continue;
+            const float bo = p.bias ? p.bias[o] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int rg = 0; rg < 16; ++rg) {
-                const long r = r0 + wm * 64 + i * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * half;
-                if (r >= p.R) continue;
-                float v = acc[i][j][rg] + bo;
-                if (p.row_scale) {
-                    const int ch = (int)((r / p.rows_per_ch) % p.n_ch);
-                    v = v * p.row_scale[ch] + p.row_shift[ch];
+            for (int i = 0; i < 2; ++i) {
+                const long rt = r0 + wm * 64 + i * 32;
+                float sc = 1.f, sh = 0.f;
+                if (ch_per_tile) {
+                    const int ch = (int)((rt / p.rows_per_ch) % p.n_ch);
+                    sc = p.row_scale[ch]; sh = p.row_shift[ch];
                 }
-                v = apply_act(v, p.act, 0.f);
-                if (p.res) v += p.res[r * p.ldr + o];
-                p.c[r * p.ldc + o] = v;
+                float rv[16];
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const long r = rt + (rg & 3) + 8 * (rg >> 2) + 4 * half;
+                    rv[rg] = (p.res && r < p.R) ? p.res[r * p.ldr + o] : 0.f;
+                }
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const long r = rt + (rg & 3) + 8 * (rg >> 2) + 4 * half;
+                    if (r >= p.R) continue;
+                    float v = acc[i][j][rg] + bo;
+                    if (p.row_scale && !ch_per_tile) {
+                        const int ch = (int)((r / p.rows_per_ch) % p.n_ch);
+                        sc = p.row_scale[ch]; sh = p.row_shift[ch];
+                    }
+                    v = v * sc + sh;
+                    v = ACT == 0 ? v : ACT == 1 ? (v > 0.f ? v : 0.f) : apply_act(v, p.act, 0.f);
+                    p.c[r * p.ldc + o] = v + rv[rg];
+                }
             }
-    }
+        }
+    };
+    if (p.act == AICG_ACT_NONE) epilogue(std::integral_constant<int, 0>{});
+    else if (p.act == AICG_ACT_RELU) epilogue(std::integral_constant<int, 1>{});
+    else epilogue(std::integral_constant<int, 2>{});
 }
 
 }  // namespace aicg
