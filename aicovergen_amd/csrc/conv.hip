@@ -179,6 +179,13 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
     p.dbg = ablate;
     // narrow layers (16 / 48 output channels, at least 3 input channels, enough positions): 16x16x4 MFMA tiles
     static const bool use16 = getenv("AICG_CONV_M16") ? atoi(getenv("AICG_CONV_M16")) != 0 : true;
+    static const int v3m16 = getenv("AICG_CONV_V3M16") ? atoi(getenv("AICG_CONV_V3M16")) : 1;
+    if (use16 && v3m16 && p.w3 && p.Cin_g >= 16 && npos >= 256L * 256) {
+        int rc = 1;
+        if (M > 32 && M <= 48) rc = run_ws3m16_48(p, (hipStream_t)stream);
+        else if (M <= 16) rc = run_ws3m16_16(p, (hipStream_t)stream);
+        if (rc <= 0) return rc;
+    }
     if (use16 && p.Cin_g >= 3 && npos >= 256L * 256) {
         int rc = 1;
         if (M > 32 && M <= 48) rc = run_m16_48(p, st);

@@ -67,6 +67,7 @@ struct ConvArgs {
     // loop halving the matrix pipe, both in their epilogue with the pipe idle (r2 in-kernel timeline: 17 % of a 96-row MDX
     // tile's lifetime); half a tile out of phase, one workgroup's prologue / epilogue runs under the other's MFMAs.
     int stagger, stagger_first;
+    int wide_ok;   // y (and res) rows are 16-byte aligned and TW % 4 == 0: interior tiles may use the float4 epilogue
     int dbg;  // AICG_CONV_ABLATE bits (profiling only): 1 no global loads, 2 no LDS commit, 4 no barriers, 8 no MFMA loop, 16 no epilogue
 };
 
@@ -717,6 +718,83 @@ __device__ __forceinline__ void ws_epilogue32(const ConvArgs& p, f32x16 (&acc)[T
     dispatch_epilogue(p.act, interior, epilogue);
 }
 
+
+// Interior tiles, plain output addressing, 16-byte-aligned rows: the float4 epilogue.
+// In the MFMA accumulator layout a lane owns ONE position and 16 rows per 32 x 32 tile: a tile costs 16 dword stores per lane (plus
+// 16 + 16 dword loads with a residual / accumulate operand), and the tail of a tile is bound by the NUMBER of global memory
+// instructions, not by bytes (r2 timeline: 38.5k cycles for the 48 stores of a 96 x 128 tile's wave, ~800 cycles per instruction
+// -- cf. MI355X guide T21).  Each 32 x 32 tile therefore takes a detour through a per-wave LDS scratch (16 ds_write_b32, 4
+// ds_read_b128) that turns the layout into 4 consecutive positions per lane: 4 global_store_dwordx4 per tile, 8 rows x 128 B each.
+static constexpr int kEpiRow = 36;                 // scratch row stride in floats (32 + 4: keeps float4 alignment, spreads banks)
+static constexpr int kEpiScratch = 32 * kEpiRow;   // floats per consumer wave
+template <int TM, int TN>
+__device__ __forceinline__ void ws_epilogue32_wide(const ConvArgs& p, f32x16 (&acc)[TM][TN], int n, int g, int m_wave0, int nl0, int h0,
+                                                   int w0, int lane, float* scratch) {
+    const int l31 = lane & 31, half = lane >> 5;
+    const int rrow = lane >> 3, rcol = (lane & 7) * 4;   // after the detour: rows rrow + 8 pass, positions rcol .. rcol + 3
+    float* wr = scratch + (4 * half) * kEpiRow + l31;
+    const float4* rd = reinterpret_cast<const float4*>(scratch + rrow * kEpiRow + rcol);
+    auto body = [&](auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nl = nl0 + j * 32 + rcol;
+            const int ho = h0 + (nl >> p.TWlog2), wo = w0 + (nl & (p.TW - 1));
+            const long y_col = (long)n * p.y_sn + (long)ho * p.y_sh + wo, r_col = (long)n * p.r_sn + (long)ho * p.r_sh + wo;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                __builtin_amdgcn_wave_barrier();   // (scheduling fence; the emulator's lanes rendezvous: previous tile fully read)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) wr[((r & 3) + 8 * (r >> 2)) * kEpiRow] = acc[i][j][r];
+                __builtin_amdgcn_wave_barrier();   // all lanes' rows written before any lane reads across them
+                const long co0 = (long)g * p.Cout_g + m_wave0 + i * 32 + rrow;
+                float4 rv[4], yv[4], v[4];
+                if (p.res) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) rv[q] = *reinterpret_cast<const float4*>(p.res + r_col + (co0 + 8 * q) * p.r_sc);
+                }
+                if (p.accumulate) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) yv[q] = *reinterpret_cast<const float4*>(p.y + y_col + (co0 + 8 * q) * p.y_sc);
+                }
+                // (a wave's LDS accesses are processed in order: no s_barrier between its own writes and reads)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = rd[q * 8 * (kEpiRow / 4)];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+                    const float rr[4] = {p.res ? rv[q].x : 0.f, p.res ? rv[q].y : 0.f, p.res ? rv[q].z : 0.f, p.res ? rv[q].w : 0.f};
+                    const float yy[4] = {p.accumulate ? yv[q].x : 0.f, p.accumulate ? yv[q].y : 0.f, p.accumulate ? yv[q].z : 0.f,
+                                         p.accumulate ? yv[q].w : 0.f};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        float x = e[t];
+                        if (p.res_first) x += rr[t];
+                        x = act_static<ACT>(x, p.act, p.act_slope);
+                        if (!p.res_first) x += rr[t];
+                        e[t] = x * p.out_scale + yy[t];
+                    }
+                    *reinterpret_cast<float4*>(p.y + y_col + (co0 + 8 * q) * p.y_sc) = make_float4(e[0], e[1], e[2], e[3]);
+                }
+            }
+        }
+    };
+    if (p.act == AICG_ACT_NONE) body(std::integral_constant<int, 0>{});
+    else if (p.act == AICG_ACT_RELU) body(std::integral_constant<int, 1>{});
+    else if (p.act == AICG_ACT_LRELU) body(std::integral_constant<int, 2>{});
+    else body(std::integral_constant<int, 3>{});
+}
+
+// host side: may interior tiles of this launch use ws_epilogue32_wide?
+inline int conv_wide_ok(const ConvArgs& p) {
+    auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    auto m4 = [](long v) { return (v & 3) == 0; };
+    if (p.shuffle || p.res_mul || (p.TW & 3)) return 0;
+    if (!al(p.y) || !m4(p.y_sn) || !m4(p.y_sc) || !m4(p.y_sh)) return 0;
+    if (p.res && (!al(p.res) || !m4(p.r_sn) || !m4(p.r_sc) || !m4(p.r_sh))) return 0;
+    return 1;
+}
+
 // GEN: instantiation for shuffle / multiplicative-residual layers (runtime-generic output addressing); kept out of the plain
 // instantiation, whose register allocation it would disturb.
 template <int BM, int BN, int WM, int WN, int XR, int KS, bool GEN>
@@ -835,9 +913,97 @@ __global__ void __launch_bounds__(64 * (WM * WN + 4), (WM * WN == 4 ? 4 : 3)) co
     if (kAblate && (p.dbg & 16)) { if (acc[0][0][0] != 12345.f) return; }
 
     const bool interior = m_base + BM <= p.Cout_g && h0 + p.TH <= p.Ho && w0 + p.TW <= p.Wo;
-    ws_epilogue32<TM, TN, GEN>(p, acc, n, g, m_base + wm * (TM * 32), wn * (TN * 32), h0, w0, l31, half, interior);
+    if (!GEN && interior && p.wide_ok) {
+        lds_barrier();   // consumers only (the producers have exited): every wave is done with the last stage, LDS is free
+        ws_epilogue32_wide<TM, TN>(p, acc, n, g, m_base + wm * (TM * 32), wn * (TN * 32), h0, w0, lane, smem + wave * kEpiScratch);
+    } else {
+        ws_epilogue32<TM, TN, GEN>(p, acc, n, g, m_base + wm * (TM * 32), wn * (TN * 32), h0, w0, l31, half, interior);
+    }
     trace_mark(trace_wg, 3);
     trace_val(trace_wg, 4, (unsigned long long)nstages);
+}
+
+// ---- shared by the 16x16x4 wave-specialised kernels -----------------------------------------------------------------------------
+// Lane (r16, q) owns, per 16 x 16 tile (i, j), rows m_base + 16 i + 4 q + r (r = 0..3) of column nl0 + 16 j + r16.
+template <int TM, int TN>
+__device__ __forceinline__ void ws_init_acc16(const ConvArgs& p, f32x4 (&acc)[TM][TN], int g, int m_base, int q) {
+    if (p.bias) {  // all bias loads first, then the (masked) broadcast over the column tiles
+        const float* bp = p.bias + g * p.Cout_g;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m_base + i * 16 + q * 4 + r;
+                acc[i][0][r] = bp[m < p.Cout_g ? m : 0];
+            }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m_base + i * 16 + q * 4 + r;
+                const float b = m < p.Cout_g ? acc[i][0][r] : 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j][r] = b;
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+    }
+}
+
+template <int TM, int TN, bool GEN>
+__device__ __forceinline__ void ws_epilogue16(const ConvArgs& p, f32x4 (&acc)[TM][TN], int n, int g, int m_base, int nl0, int h0, int w0,
+                                              int r16, int q, bool interior) {
+    const long y_base = (long)n * p.y_sn, r_base = (long)n * p.r_sn;
+    auto epilogue = [&](auto full_tag, auto act_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int nl = nl0 + j * 16 + r16;
+            const int ho = h0 + (nl >> p.TWlog2), wo = w0 + (nl & (p.TW - 1));
+            const bool col_ok = FULL || (ho < p.Ho && wo < p.Wo);
+            const long y_col = y_base + (long)ho * p.y_sh + wo, r_col = r_base + (long)ho * p.r_sh + wo;
+            float rv[TM * 4], yv[TM * 4];
+#pragma unroll
+            for (int e = 0; e < TM * 4; ++e) { rv[e] = 0.f; yv[e] = 0.f; }
+            if (p.res) {
+#pragma unroll
+                for (int e = 0; e < TM * 4; ++e) {
+                    const int m = m_base + (e >> 2) * 16 + q * 4 + (e & 3);
+                    const bool ok = FULL || (col_ok && m < p.Cout_g);
+                    const float t = p.res[ok ? (GEN ? r_base + out_index(p, g * p.Cout_g + m, ho, wo, p.r_sc, p.r_sh) : r_col + (long)(g * p.Cout_g + m) * p.r_sc) : 0];
+                    rv[e] = ok ? t : 0.f;
+                }
+            }
+            if (p.accumulate) {
+#pragma unroll
+                for (int e = 0; e < TM * 4; ++e) {
+                    const int m = m_base + (e >> 2) * 16 + q * 4 + (e & 3);
+                    const bool ok = FULL || (col_ok && m < p.Cout_g);
+                    const float t = p.y[ok ? (GEN ? y_base + out_index(p, g * p.Cout_g + m, ho, wo, p.y_sc, p.y_sh) : y_col + (long)(g * p.Cout_g + m) * p.y_sc) : 0];
+                    yv[e] = ok ? t : 0.f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < TM * 4; ++e) {
+                const int m = m_base + (e >> 2) * 16 + q * 4 + (e & 3);
+                if (!FULL && !(col_ok && m < p.Cout_g)) continue;
+                float v = acc[e >> 2][j][e & 3];
+                if (p.res_first) v += rv[e];
+                v = act_static<ACT>(v, p.act, p.act_slope);
+                if (!p.res_first) v = (GEN && p.res_mul) ? v * rv[e] : v + rv[e];
+                v = v * p.out_scale + yv[e];
+                if (GEN) p.y[y_base + out_index(p, g * p.Cout_g + m, ho, wo, p.y_sc, p.y_sh)] = v;
+                else p.y[y_col + (long)(g * p.Cout_g + m) * p.y_sc] = v;
+            }
+        }
+    };
+    dispatch_epilogue(p.act, interior, epilogue);
 }
 
 // Wave-specialised narrow-M kernel: the consumers of conv_mfma16_kernel (16x16x4 MFMA, every wave covers all BM rows x 64
@@ -875,32 +1041,7 @@ __global__ void __launch_bounds__(512, 4) conv_ws16_kernel(ConvArgs p) {
         boff[j] = jh * p.sh * p.TWp + jw * p.sw + q * p.CHS;
     }
     f32x4 acc[TM][TN];
-    if (p.bias) {  // all bias loads first, then the (masked) broadcast over the column tiles
-        const float* bp = p.bias + g * p.Cout_g;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m_base + i * 16 + q * 4 + r;
-                acc[i][0][r] = bp[m < p.Cout_g ? m : 0];
-            }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m_base + i * 16 + q * 4 + r;
-                const float b = m < p.Cout_g ? acc[i][0][r] : 0.f;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j][r] = b;
-            }
-    } else {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-    }
+    ws_init_acc16<TM, TN>(p, acc, g, m_base, q);
     {
         int c = 0, tap0 = 0;
         for (int st = 0; st < nstages; ++st) {
@@ -944,53 +1085,8 @@ __global__ void __launch_bounds__(512, 4) conv_ws16_kernel(ConvArgs p) {
             if (tap0 >= p.taps) { tap0 = 0; ++c; }
         }
     }
-    const long y_base = (long)n * p.y_sn, r_base = (long)n * p.r_sn;
     const bool interior = m_base + BM <= p.Cout_g && h0 + p.TH <= p.Ho && w0 + p.TW <= p.Wo;
-    auto epilogue = [&](auto full_tag, auto act_tag) {
-        constexpr bool FULL = decltype(full_tag)::value;
-        constexpr int ACT = decltype(act_tag)::value;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int nl = wn * 64 + j * 16 + r16;
-            const int ho = h0 + (nl >> p.TWlog2), wo = w0 + (nl & (p.TW - 1));
-            const bool col_ok = FULL || (ho < p.Ho && wo < p.Wo);
-            const long y_col = y_base + (long)ho * p.y_sh + wo, r_col = r_base + (long)ho * p.r_sh + wo;
-            float rv[TM * 4], yv[TM * 4];
-#pragma unroll
-            for (int e = 0; e < TM * 4; ++e) { rv[e] = 0.f; yv[e] = 0.f; }
-            if (p.res) {
-#pragma unroll
-                for (int e = 0; e < TM * 4; ++e) {
-                    const int m = m_base + (e >> 2) * 16 + q * 4 + (e & 3);
-                    const bool ok = FULL || (col_ok && m < p.Cout_g);
-                    const float t = p.res[ok ? (GEN ? r_base + out_index(p, g * p.Cout_g + m, ho, wo, p.r_sc, p.r_sh) : r_col + (long)(g * p.Cout_g + m) * p.r_sc) : 0];
-                    rv[e] = ok ? t : 0.f;
-                }
-            }
-            if (p.accumulate) {
-#pragma unroll
-                for (int e = 0; e < TM * 4; ++e) {
-                    const int m = m_base + (e >> 2) * 16 + q * 4 + (e & 3);
-                    const bool ok = FULL || (col_ok && m < p.Cout_g);
-                    const float t = p.y[ok ? (GEN ? y_base + out_index(p, g * p.Cout_g + m, ho, wo, p.y_sc, p.y_sh) : y_col + (long)(g * p.Cout_g + m) * p.y_sc) : 0];
-                    yv[e] = ok ? t : 0.f;
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < TM * 4; ++e) {
-                const int m = m_base + (e >> 2) * 16 + q * 4 + (e & 3);
-                if (!FULL && !(col_ok && m < p.Cout_g)) continue;
-                float v = acc[e >> 2][j][e & 3];
-                if (p.res_first) v += rv[e];
-                v = act_static<ACT>(v, p.act, p.act_slope);
-                if (!p.res_first) v = (GEN && p.res_mul) ? v * rv[e] : v + rv[e];
-                v = v * p.out_scale + yv[e];
-                if (GEN) p.y[y_base + out_index(p, g * p.Cout_g + m, ho, wo, p.y_sc, p.y_sh)] = v;
-                else p.y[y_col + (long)(g * p.Cout_g + m) * p.y_sc] = v;
-            }
-        }
-    };
-    dispatch_epilogue(p.act, interior, epilogue);
+    ws_epilogue16<TM, TN, GEN>(p, acc, n, g, m_base, wn * 64, h0, w0, r16, q, interior);
 }
 
 inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
@@ -1104,9 +1200,13 @@ static int launch_conv_ws(ConvArgs& p, hipStream_t stream) {
     dim3 block(64 * (WM * WN + 4));
     const bool gen = p.shuffle || p.res_mul;
     p.stagger = p.stagger_first = 0;
+    {
+        static const int wide = getenv("AICG_CONV_WIDE") ? atoi(getenv("AICG_CONV_WIDE")) : 1;
+        p.wide_ok = wide && (size_t)(WM * WN) * kEpiScratch * sizeof(float) <= lds ? conv_wide_ok(p) : 0;
+    }
 #ifndef AICG_EMULATED
     {
-        static const int stag = getenv("AICG_CONV_STAGGER") ? atoi(getenv("AICG_CONV_STAGGER")) : 1;
+        static const int stag = getenv("AICG_CONV_STAGGER") ? atoi(getenv("AICG_CONV_STAGGER")) : 0;
         const long nwg = gx * idiv_up(p.Cout_g, BM) * p.groups;
         const int per_cu = (int)((160 * 1024) / lds);
         if (stag && WM * WN == 4 && per_cu == 2 && nwg >= 8L * 512) {   // >= 8 rounds: the one-off delay costs < 1/16 of the launch

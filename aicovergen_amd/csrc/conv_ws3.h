@@ -176,14 +176,38 @@ __global__ void __launch_bounds__(64 * (WM * WN + 4), (WM * WN == 4 ? 4 : 3)) co
         const int jh = nl >> p.TWlog2, jw = nl & (p.TW - 1);
         boff[j] = jh * p.sh * p.TWp + jw * p.sw + half * p.CHS;
     }
+#ifdef AICG_CONV_TRACE
+    const int trace_wg = (wave == 0 && blockIdx.y == 0 && blockIdx.z == 0) ? (int)blockIdx.x : (1 << 30);
+    trace_mark(trace_wg, 0);
+    trace_val(trace_wg, 5, __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));   // HW_REG_HW_ID
+#else
+    const int trace_wg = 0;
+#endif
+    if (CW == 4 && p.stagger > 0) {   // see ConvArgs::stagger
+        const unsigned flat = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (flat < (unsigned)p.stagger_first) {
+            // spread the initial fill over one tile time (all CUs otherwise run their prologue loads / epilogue stores as one burst)
+            const unsigned long long delay = (unsigned long long)p.stagger * ((flat * 37u) & 63u) / 64u;
+            const unsigned long long t0 = __builtin_readcyclecounter();
+            while (__builtin_readcyclecounter() - t0 < delay) __builtin_amdgcn_s_sleep(64);
+        }
+    }
+    trace_mark(trace_wg, 6);
     f32x16 acc[TM][TN];
     ws_init_acc32<TM, TN>(p, acc, g, m_base + wm * (TM * 32), half);
     const int a_off = wm * (TM * 32) + l31 + half * BM;   // float4 index inside a slab pair
+#ifdef AICG_CONV_TRACE
+    if (acc[0][0][0] == 1.2345e-30f) return;
+#endif
+    trace_mark(trace_wg, 7);
     {
         int c = 0, tap0 = 0;
         const int gpt = p.BKC >> 3;   // k-groups per tap
         for (int st = 0; st < nstages; ++st) {
+            trace2(trace_wg, 0, st, 0);
             lds_barrier();  // stage st is in LDS
+            trace2(trace_wg, 0, st, 1);
+            if (st == 0) trace_mark(trace_wg, 1);
             const float4* xs = reinterpret_cast<const float4*>(xs0 + (c & 1) * XS_ELEMS);
             const float4* wt = reinterpret_cast<const float4*>(ws0 + (st & 1) * WS_ELEMS) + a_off;
             const int nt = imin(p.TT, p.taps - tap0);
@@ -229,8 +253,16 @@ __global__ void __launch_bounds__(64 * (WM * WN + 4), (WM * WN == 4 ? 4 : 3)) co
             if (tap0 >= p.taps) { tap0 = 0; ++c; }
         }
     }
+    trace_mark(trace_wg, 2);
     const bool interior = m_base + BM <= p.Cout_g && h0 + p.TH <= p.Ho && w0 + p.TW <= p.Wo;
-    ws_epilogue32<TM, TN, GEN>(p, acc, n, g, m_base + wm * (TM * 32), wn * (TN * 32), h0, w0, l31, half, interior);
+    if (!GEN && interior && p.wide_ok) {
+        lds_barrier();   // consumers only (the producers have exited): every wave is done with the last stage, LDS is free
+        ws_epilogue32_wide<TM, TN>(p, acc, n, g, m_base + wm * (TM * 32), wn * (TN * 32), h0, w0, lane, smem + wave * kEpiScratch);
+    } else {
+        ws_epilogue32<TM, TN, GEN>(p, acc, n, g, m_base + wm * (TM * 32), wn * (TN * 32), h0, w0, l31, half, interior);
+    }
+    trace_mark(trace_wg, 3);
+    trace_val(trace_wg, 4, (unsigned long long)nstages);
 }
 
 // returns 0 launched, < 0 error, 1 the configuration does not fit this form
@@ -272,11 +304,167 @@ static int launch_conv_ws3(ConvArgs& p, hipStream_t stream) {
     dim3 block(64 * (WM * WN + 4));
     const bool gen = p.shuffle || p.res_mul;
     p.stagger = p.stagger_first = 0;
+    {
+        static const int wide = getenv("AICG_CONV_WIDE") ? atoi(getenv("AICG_CONV_WIDE")) : 1;
+        p.wide_ok = wide && (size_t)(WM * WN) * kEpiScratch * sizeof(float) <= lds ? conv_wide_ok(p) : 0;
+    }
+#ifndef AICG_EMULATED
+    {
+        static const int stag = getenv("AICG_CONV_STAGGER") ? atoi(getenv("AICG_CONV_STAGGER")) : 0;
+        const long nwg = gx * idiv_up(p.Cout_g, BM) * p.groups;
+        const int per_cu = (int)((160 * 1024) / lds);
+        if (stag && WM * WN == 4 && per_cu == 2 && nwg >= 8L * 512) {   // >= 8 rounds: the one-off delay costs < 1/16 of the launch
+            const long groups_k = (long)p.nchunk * p.taps * (p.BKC / 8);
+            const long floor_cycles = groups_k * 4 * (BM / (32 * WM)) * (BN / (32 * WN)) * 64;   // MFMA issue time of one tile
+            p.stagger = (int)(lmin(floor_cycles, 1L << 22) * stag / 100);
+            p.stagger_first = 512;
+        }
+    }
+#endif
     auto kern = gen ? (xq == 2 ? conv_ws3_kernel<BM, BN, WM, WN, 2, KS, true> : conv_ws3_kernel<BM, BN, WM, WN, 3, KS, true>)
                     : (xq == 2 ? conv_ws3_kernel<BM, BN, WM, WN, 2, KS, false> : conv_ws3_kernel<BM, BN, WM, WN, 3, KS, false>);
     allow_dynamic_lds((const void*)kern, lds);
     hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
     return check_launch("conv_ws3_kernel");
+}
+
+
+// ---- 16x16x4 form for 48- / 16-row layers (MDX-Net level 0, RMVPE level 0) -------------------------------------------------------
+// v_mfma_f32_16x16x4_f32: lane (r16, q) supplies A[m = r16][k-slot q] and B[k-slot q][n = r16] of a 4-row k-step.  WHICH four
+// rows of K form a k-step is free as long as both operands agree, so the k8-interleaved layouts above serve unchanged: of a
+// 16-row K group (= two 8-groups, four (group, parity) planes) lane q reads plane q; element u of its float4 is row
+// 8 (q >> 1) + 2 u + (q & 1), and k-step u contracts the four rows {2 u, 2 u + 1, 8 + 2 u, 9 + 2 u}.  One ds_read_b128 per fragment
+// per FOUR k-steps here too.  Every consumer wave covers all BM rows x 64 positions of a 256-position tile.
+template <int BM, int XQ, int KS, bool GEN>
+__global__ void __launch_bounds__(512, 4) conv_ws3m16_kernel(ConvArgs p) {
+    constexpr int CNT = 256;
+    constexpr int TM = BM / 16, TN = 4;
+    constexpr int WS_ELEMS = Ws3Geom<BM, KS>::WS_ELEMS;
+    constexpr int XS_ELEMS = XQ * 256 * 4;
+    HIP_DYNAMIC_SHARED(float, smem)
+    float* const xs0 = smem;
+    float* const ws0 = smem + 2 * XS_ELEMS;
+    const int tid = threadIdx.x;
+    const int bx = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int tw_i = bx % p.tiles_w;
+    const int th_i = (bx / p.tiles_w) % p.tiles_h;
+    const int n = bx / (p.tiles_w * p.tiles_h);
+    const int w0 = tw_i * p.TW, h0 = th_i * p.TH;
+    const int m_base = blockIdx.y * BM;
+    const int g = blockIdx.z;
+    const int stages_per_chunk = (p.taps + p.TT - 1) / p.TT;
+    const int nstages = p.nchunk * stages_per_chunk;
+    if (tid >= CNT) {
+        ws3_produce<BM, XQ, KS, false>(p, xs0, ws0, tid - CNT, n, g, h0, w0, m_base, nstages);
+        return;
+    }
+    const int lane = tid & 63, wn = tid >> 6;
+    const int q = lane >> 4, r16 = lane & 15;
+    int boff[TN];   // float4 index inside a 16-row group's four planes
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nl = wn * 64 + j * 16 + r16;
+        const int jh = nl >> p.TWlog2, jw = nl & (p.TW - 1);
+        boff[j] = jh * p.sh * p.TWp + jw * p.sw + q * p.CHS;
+    }
+    f32x4 acc[TM][TN];
+    ws_init_acc16<TM, TN>(p, acc, g, m_base, q);
+    const int a_off = q * BM + r16;
+    {
+        int c = 0, tap0 = 0;
+        const int gpt = p.BKC >> 4;   // 16-row groups per tap
+        for (int st = 0; st < nstages; ++st) {
+            lds_barrier();  // stage st is in LDS
+            const float4* xs = reinterpret_cast<const float4*>(xs0 + (c & 1) * XS_ELEMS);
+            const float4* wt = reinterpret_cast<const float4*>(ws0 + (st & 1) * WS_ELEMS) + a_off;
+            const int nt = imin(p.TT, p.taps - tap0);
+            const int ngroups = nt * gpt;
+            const int kh0 = tap0 / p.KW;
+            int kw = tap0 - kh0 * p.KW, gg = 0;
+            int xoff = kh0 * p.dh * p.TWp + kw * p.dw;
+            const int step_g = 4 * p.CHS, next_tap = p.dw - gpt * 4 * p.CHS, next_row = p.dh * p.TWp - p.KW * p.dw;
+            float4 a0[TM], b0[TN], a1[TM], b1[TN];
+            auto fetch = [&](float4 (&a)[TM], float4 (&b)[TN], int s) {
+                const float4* xt = xs + xoff;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = wt[s * 4 * BM + i * 16];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = xt[boff[j]];
+                xoff += step_g;
+                if (++gg == gpt) { gg = 0; xoff += next_tap; if (++kw == p.KW) { kw = 0; xoff += next_row; } }
+            };
+            auto mma = [&](float4 (&a)[TM], float4 (&b)[TN]) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            const float av = u == 0 ? a[i].x : u == 1 ? a[i].y : u == 2 ? a[i].z : a[i].w;
+                            const float bv = u == 0 ? b[j].x : u == 1 ? b[j].y : u == 2 ? b[j].z : b[j].w;
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i][j], 0, 0, 0);
+                        }
+            };
+            fetch(a0, b0, 0);
+            int s = 0;
+            for (; s + 2 <= ngroups; s += 2) {
+                fetch(a1, b1, s + 1);
+                mma(a0, b0);
+                if (s + 2 < ngroups) fetch(a0, b0, s + 2);  // a 16-row group past the stage would overrun the 8 slack rows
+                mma(a1, b1);
+            }
+            if (s < ngroups) mma(a0, b0);
+            tap0 += p.TT;
+            if (tap0 >= p.taps) { tap0 = 0; ++c; }
+        }
+    }
+    const bool interior = m_base + BM <= p.Cout_g && h0 + p.TH <= p.Ho && w0 + p.TW <= p.Wo;
+    ws_epilogue16<TM, TN, GEN>(p, acc, n, g, m_base, wn * 64, h0, w0, r16, q, interior);
+}
+
+template <int BM>
+static int launch_conv_ws3m16(ConvArgs& p, hipStream_t stream) {
+    constexpr int BN = 256, KS = KSTAGE;
+    if (p.Cin_g < 16 || !p.w3) return 1;
+    p.TW = choose_tile_width(p, BN);
+    p.TWlog2 = ilog2(p.TW);
+    p.TH = BN / p.TW;
+    p.TH_in = (p.TH - 1) * p.sh + (p.KH - 1) * p.dh + 1;
+    p.TW_in = (p.TW - 1) * p.sw + (p.KW - 1) * p.dw + 1;
+    p.TWp = p.TW_in | 1;
+    p.CHS = p.TH_in * p.TWp;
+    p.tiles_w = idiv_up(p.Wo, p.TW);
+    p.tiles_h = idiv_up(p.Ho, p.TH);
+    p.BKC = 32;
+    // patch budget: 6 quads per producer thread (24 KB per buffer) -- a 256-position 2-D tile with its halo is ~350 positions
+    // and a k-step group needs 16 channels of it
+    while (p.BKC > 16 && (p.BKC * p.CHS > 24 * 256 || p.BKC >= 2 * p.Cin_g)) p.BKC >>= 1;
+    p.BKClog2 = ilog2(p.BKC);
+    {
+        const int cap = imax(1, KS / p.BKC);
+        const int nstg = idiv_up(p.taps, cap);
+        p.TT = idiv_up(p.taps, nstg);
+    }
+    p.nchunk = idiv_up(p.Cin_g, p.BKC);
+    p.xs_total = p.BKC * p.CHS;
+    p.xs_elems = (p.xs_total + 3) & ~3;
+    p.div_chs = div_mul(p.CHS);
+    p.div_twp = div_mul(p.TWp);
+    if (p.xs_total > 24 * 256) return 1;
+    const int xq = idiv_up(p.xs_total / 4, 256) <= 3 ? 3 : 6;
+    const size_t lds = (size_t)(2 * xq * 256 * 4 + 2 * Ws3Geom<BM, KS>::WS_ELEMS) * sizeof(float);
+    const bool off_ok = (long)(p.BKC + 8) * p.x_sc + (long)p.H * p.x_sh < (1L << 29) && (long)p.taps * p.Cin_pad * p.Mpad < (1L << 29);
+    if (lds > 160 * 1024 || !off_ok || (long)p.xs_total * p.CHS >= (1L << 32)) return 1;
+    const long gx = (long)p.N * p.tiles_h * p.tiles_w;
+    if (gx > 2147483647L) return fail(AICG_E_SHAPE, "conv: too many output tiles");
+    dim3 grid((unsigned)gx, (unsigned)idiv_up(p.Cout_g, BM), (unsigned)p.groups);
+    const bool gen = p.shuffle || p.res_mul;
+    p.stagger = p.stagger_first = 0;
+    auto kern = gen ? (xq == 3 ? conv_ws3m16_kernel<BM, 3, KS, true> : conv_ws3m16_kernel<BM, 6, KS, true>)
+                    : (xq == 3 ? conv_ws3m16_kernel<BM, 3, KS, false> : conv_ws3m16_kernel<BM, 6, KS, false>);
+    allow_dynamic_lds((const void*)kern, lds);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, p);
+    return check_launch("conv_ws3m16_kernel");
 }
 
 // instantiation units (conv_ws3_*.hip)
@@ -286,5 +474,7 @@ int run_ws3_64x128(ConvArgs& p, hipStream_t st);    // 4 consumers (2 x 2) x (32
 int run_ws3_64x64(ConvArgs& p, hipStream_t st);     // 4 consumers (2 x 2) x (32 x 32)
 int run_ws3_32x256(ConvArgs& p, hipStream_t st);    // 4 consumers x (32 x 64)
 int run_ws3_32x128(ConvArgs& p, hipStream_t st);    // 4 consumers x (32 x 32)
+int run_ws3m16_48(ConvArgs& p, hipStream_t st);     // 16x16x4 tiles, 48 rows x 256 positions
+int run_ws3m16_16(ConvArgs& p, hipStream_t st);     //                16 rows x 256 positions
 
 }  // namespace aicg

@@ -176,3 +176,45 @@ print("fallback kernels ok")
     env = dict(os.environ, AICG_CONV_WS="0", AICG_CONV_POINTWISE="0")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "fallback kernels ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_16x16x4_fragment_kernels(dev):
+    """conv_ws3m16_kernel (16-byte fragments on v_mfma_f32_16x16x4_f32: 48- and 16-row layers with >= 65 536 positions, the MDX-Net /
+    RMVPE level-0 shapes) incl. a channel tail (40 of 48 channels in the last K chunk) and a ragged last tile."""
+    torch.manual_seed(5)
+    for (ci, co, h, w, k) in [(16, 16, 1, 70000, 3), (32, 48, 6, 11000, 1), (40, 40, 3, 22000, 3)]:
+        x = torch.randn(1, ci, h, w)
+        wt = torch.randn(co, ci, k if h > 1 else 1, k) * 0.1
+        b, r = torch.randn(co), torch.randn(1, co, h, w)
+        pad = (k // 2 if h > 1 else 0, k // 2)
+        pc = ops.PackedConv(wt, b, padding=pad, device=dev.device)
+        y = ops.conv(dev.t(x), pc, act=ops.ACT_RELU, res=dev.t(r))
+        assert rel_rms(y, F.relu(F.conv2d(x, wt, b, padding=pad)) + r) < 1e-5, (ci, co, h, w, k)
+
+
+def test_classic_wave_specialised_kernels_in_a_subprocess():
+    """With AICG_CONV_V3=0 / AICG_CONV_V3M16=0 the dispatcher uses the 4-byte-fragment kernels (conv_ws_kernel, conv_ws16_kernel),
+    which otherwise only serve layers with < 8 input channels per group and the 160-row tile."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, torch, torch.nn.functional as F
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import conftest
+conftest._bind("emu")
+from aicovergen_amd import ops
+torch.manual_seed(0)
+def rel(a, b): return float(((a - b).pow(2).sum() / b.pow(2).sum()).sqrt())
+for (n, ci, co, h, w, k) in [(1, 24, 96, 12, 200, 3), (1, 16, 16, 1, 70000, 3), (2, 33, 64, 9, 130, 3), (1, 64, 144, 1, 900, 5)]:
+    x, wt, b, r = torch.randn(n, ci, h, w), torch.randn(co, ci, k if h > 1 else 1, k) * 0.1, torch.randn(co), torch.randn(n, co, h, w)
+    pc = ops.PackedConv(wt, b, padding=(k // 2 if h > 1 else 0, k // 2))
+    y = ops.conv(x, pc, act=ops.ACT_RELU, res=r)
+    e = rel(y, F.relu(F.conv2d(x, wt, b, padding=(k // 2 if h > 1 else 0, k // 2))) + r)
+    assert e < 1e-5, (n, ci, co, h, w, k, e)
+print("classic kernels ok")
+''' % (root, os.path.join(root, "tests"))
+    env = dict(os.environ, AICG_CONV_V3="0", AICG_CONV_V3M16="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "classic kernels ok" in out.stdout, out.stdout + out.stderr
