@@ -103,6 +103,22 @@ __device__ __forceinline__ float4 buf_load_f32x4(const BufRsrc& r, unsigned voff
 #endif
 static constexpr unsigned kBufOob = 0x80000000u;  // any byte offset >= 2^31 is out of range for the buffers made here
 
+// value of the lane whose id differs in bit 0 / bit 1 (exchange inside a quad of lanes): one DPP move on the hardware
+__device__ __forceinline__ float quad_xor1(float v) {
+#ifdef AICG_EMULATED
+    return __shfl_xor(v, 1, 64);
+#else
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true));
+#endif
+}
+__device__ __forceinline__ float quad_xor2(float v) {
+#ifdef AICG_EMULATED
+    return __shfl_xor(v, 2, 64);
+#else
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E /* quad_perm [2,3,0,1] */, 0xF, 0xF, true));
+#endif
+}
+
 // block->XCD aware remap (guide T1, bijective form): consecutive logical ids share an XCD's L2.
 __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
     const unsigned nx = 8;

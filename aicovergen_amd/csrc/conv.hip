@@ -179,7 +179,9 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
     p.dbg = ablate;
     // narrow layers (16 / 48 output channels, at least 3 input channels, enough positions): 16x16x4 MFMA tiles
     static const bool use16 = getenv("AICG_CONV_M16") ? atoi(getenv("AICG_CONV_M16")) != 0 : true;
-    static const int v3m16 = getenv("AICG_CONV_V3M16") ? atoi(getenv("AICG_CONV_V3M16")) : 1;
+    // (measured r2: MDX level 0 97 vs 105 TFLOP/s, RMVPE level 0 57 vs 60 against conv_ws16_kernel -- 12 MFMAs per k-step already
+    //  amortise the fragment hand-over there, and the 16-channel groups need the larger patch: off by default)
+    static const int v3m16 = getenv("AICG_CONV_V3M16") ? atoi(getenv("AICG_CONV_V3M16")) : 0;
     if (use16 && v3m16 && p.w3 && p.Cin_g >= 16 && npos >= 256L * 256) {
         int rc = 1;
         if (M > 32 && M <= 48) rc = run_ws3m16_48(p, (hipStream_t)stream);

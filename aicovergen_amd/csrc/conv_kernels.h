@@ -626,26 +626,27 @@ __device__ __forceinline__ void ws_produce(const ConvArgs& p, float* xs0, float*
 // Lane (l31, half) of a consumer wave owns, per 32 x 32 tile (i, j), rows m0 + (r & 3) + 8 (r >> 2) + 4 half of column nl0 + 32 j + l31.
 template <int TM, int TN>
 __device__ __forceinline__ void ws_init_acc32(const ConvArgs& p, f32x16 (&acc)[TM][TN], int g, int m_wave0, int half) {
-    // the accumulators start from the bias: every load is issued before the first use (one wait for the batch instead of
-    // TM x 16 serialised round trips), and the batch overlaps the wait for the first stage
+    // The accumulators start from the bias.  A wave's rows are contiguous: lane l loads bias[m_wave0 + 64 t + l] (one or two
+    // coalesced loads per wave) and every (tile, register) slot picks its row's value up with a lane shuffle.  (r1: TM x 16
+    // serialised global loads; r2 first cut: the same loads batched -- still 16.7k cycles of a 96-row tile's prologue, the
+    // memory pipe charges per instruction.)
     if (p.bias) {
         const float* bp = p.bias + g * p.Cout_g;
+        const int lane = (int)(threadIdx.x & 63);
+        constexpr int NB = (TM * 32 + 63) / 64;
+        float breg[NB];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m0 = m_wave0 + i * 32 + 4 * half;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (r & 3) + 8 * (r >> 2);
-                acc[i][0][r] = bp[m < p.Cout_g ? m : 0];
-            }
+        for (int t = 0; t < NB; ++t) {
+            const int m = m_wave0 + 64 * t + lane;
+            const float v = bp[m < p.Cout_g ? m : 0];
+            breg[t] = m < p.Cout_g ? v : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int m0 = m_wave0 + i * 32 + 4 * half;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (r & 3) + 8 * (r >> 2);
-                const float b = m < p.Cout_g ? acc[i][0][r] : 0.f;
+                const int src = (i & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float b = __shfl(breg[i >> 1], src, 64);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j][r] = b;
             }
@@ -927,21 +928,17 @@ __global__ void __launch_bounds__(64 * (WM * WN + 4), (WM * WN == 4 ? 4 : 3)) co
 // Lane (r16, q) owns, per 16 x 16 tile (i, j), rows m_base + 16 i + 4 q + r (r = 0..3) of column nl0 + 16 j + r16.
 template <int TM, int TN>
 __device__ __forceinline__ void ws_init_acc16(const ConvArgs& p, f32x4 (&acc)[TM][TN], int g, int m_base, int q) {
-    if (p.bias) {  // all bias loads first, then the (masked) broadcast over the column tiles
+    if (p.bias) {  // one coalesced load of the tile's rows per wave, then a lane shuffle per (tile, register) slot
         const float* bp = p.bias + g * p.Cout_g;
+        const int lane = (int)(threadIdx.x & 63);
+        const int mb = m_base + lane;
+        const float bl = bp[(lane < TM * 16 && mb < p.Cout_g) ? mb : 0];
+        const float breg = (lane < TM * 16 && mb < p.Cout_g) ? bl : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m_base + i * 16 + q * 4 + r;
-                acc[i][0][r] = bp[m < p.Cout_g ? m : 0];
-            }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m_base + i * 16 + q * 4 + r;
-                const float b = m < p.Cout_g ? acc[i][0][r] : 0.f;
+                const float b = __shfl(breg, i * 16 + q * 4 + r, 64);
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j][r] = b;
             }

@@ -178,18 +178,36 @@ print("fallback kernels ok")
     assert out.returncode == 0 and "fallback kernels ok" in out.stdout, out.stdout + out.stderr
 
 
-def test_16x16x4_fragment_kernels(dev):
-    """conv_ws3m16_kernel (16-byte fragments on v_mfma_f32_16x16x4_f32: 48- and 16-row layers with >= 65 536 positions, the MDX-Net /
-    RMVPE level-0 shapes) incl. a channel tail (40 of 48 channels in the last K chunk) and a ragged last tile."""
-    torch.manual_seed(5)
-    for (ci, co, h, w, k) in [(16, 16, 1, 70000, 3), (32, 48, 6, 11000, 1), (40, 40, 3, 22000, 3)]:
-        x = torch.randn(1, ci, h, w)
-        wt = torch.randn(co, ci, k if h > 1 else 1, k) * 0.1
-        b, r = torch.randn(co), torch.randn(1, co, h, w)
-        pad = (k // 2 if h > 1 else 0, k // 2)
-        pc = ops.PackedConv(wt, b, padding=pad, device=dev.device)
-        y = ops.conv(dev.t(x), pc, act=ops.ACT_RELU, res=dev.t(r))
-        assert rel_rms(y, F.relu(F.conv2d(x, wt, b, padding=pad)) + r) < 1e-5, (ci, co, h, w, k)
+def _run_child(code, env_extra, token):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pre = "import sys, torch, torch.nn.functional as F\nsys.path.insert(0, %r); sys.path.insert(0, %r)\nimport conftest\n" \
+          "conftest._bind('emu')\nfrom aicovergen_amd import ops\ntorch.manual_seed(0)\n" \
+          "def rel(a, b): return float(((a - b).pow(2).sum() / b.pow(2).sum()).sqrt())\n" % (root, os.path.join(root, "tests"))
+    out = subprocess.run([sys.executable, "-c", pre + code], env=dict(os.environ, **env_extra), capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0 and token in out.stdout, out.stdout + out.stderr
+
+
+def test_16x16x4_fragment_kernels_in_a_subprocess():
+    """conv_ws3m16_kernel (16-byte fragments on v_mfma_f32_16x16x4_f32; opt-in through AICG_CONV_V3M16=1: 48- and 16-row layers with
+    >= 65 536 positions, the MDX-Net / RMVPE level-0 shapes) incl. a channel tail (40 of 48 channels in the last K chunk) and a
+    ragged last tile."""
+    code = r'''
+for (ci, co, h, w, k) in [(16, 16, 1, 70000, 3), (32, 48, 6, 11000, 1), (40, 40, 3, 22000, 3)]:
+    x = torch.randn(1, ci, h, w)
+    wt = torch.randn(co, ci, k if h > 1 else 1, k) * 0.1
+    b, r = torch.randn(co), torch.randn(1, co, h, w)
+    pad = (k // 2 if h > 1 else 0, k // 2)
+    pc = ops.PackedConv(wt, b, padding=pad)
+    y = ops.conv(x, pc, act=ops.ACT_RELU, res=r)
+    e = rel(y, F.relu(F.conv2d(x, wt, b, padding=pad)) + r)
+    assert e < 1e-5, (ci, co, h, w, k, e)
+print("m16 fragment kernels ok")
+'''
+    _run_child(code, {"AICG_CONV_V3M16": "1"}, "m16 fragment kernels ok")
 
 
 def test_classic_wave_specialised_kernels_in_a_subprocess():
