@@ -14,6 +14,7 @@ from . import ops
 
 WINDOW, PITCH_BINS = 1024, 360
 BN_EPS = 0.0010000000474974513
+DITHER = None   # tests: callable n_frames -> cents offsets replacing torchcrepe's random triangular dither everywhere
 
 
 def _freq_to_bin(freq, ceil=False):
@@ -91,6 +92,8 @@ def predict(net, audio, hop, fmin=50.0, fmax=1100.0, batch_size=None, dither=Non
     bins = ops.crepe_viterbi(probs, lens, _freq_to_bin(fmin), _freq_to_bin(fmax, ceil=True))
     bins = torch.cat([bins[s, :lens[s]] for s in range(n_seq)])
     cents = (20 * bins + 1997.3794084376191).float()
+    if dither is None and DITHER is not None:
+        dither = DITHER(bins.numel())
     if dither is None:
         u = torch.rand(2, bins.numel(), device=dev)
         dither = (u[0] + u[1] - 1.0) * 20.0                                # triangular on (-20, 20) cents
@@ -108,3 +111,18 @@ def mangio_crepe_f0(net, x, p_len, hop, dither=None):
     source[source < 0.001] = np.nan
     target = np.interp(np.arange(0, len(source) * p_len, len(source)) / p_len, np.arange(0, len(source)), source)
     return np.nan_to_num(target)
+
+
+def official_crepe_f0(net, x, hop, fmin=50.0, fmax=1100.0, dither=None):
+    """VC.get_f0_official_crepe_computation (reference src/vc_infer_pipeline.py:139-165):
+    f0, pd = torchcrepe.predict(audio, 16000, hop, fmin, fmax, model, batch_size=512, return_periodicity=True);
+    pd = torchcrepe.filter.median(pd, 3); f0 = torchcrepe.filter.mean(f0, 3); f0[pd < 0.1] = 0.
+    The periodicity is the posterior at the Viterbi-decoded bin (torchcrepe.core.periodicity); both 3-frame filters run in
+    ops.filter3 (wave-shuffle neighbours)."""
+    x = np.asarray(x, dtype=np.float32)
+    pitch, bins, post = predict(net, x, hop, fmin, fmax, batch_size=512, dither=dither)
+    pd = post.gather(1, bins.view(-1, 1)).view(-1)
+    pd = ops.filter3(pd, "median")
+    f0 = ops.filter3(pitch, "mean")
+    f0 = torch.where(pd < 0.1, torch.zeros_like(f0), f0)
+    return f0.cpu().numpy()

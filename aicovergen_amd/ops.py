@@ -687,3 +687,130 @@ def crepe_viterbi(probs, seq_len, bin_lo, bin_hi):
     _call("aicg_crepe_viterbi", _ptr(probs), _ptr(sl), _ptr(logp), _ptr(ptr), _ptr(bins), n_seq, nb, ms, int(bin_lo),
               int(bin_hi), _stream(probs))
     return bins
+
+
+# ---------------------------------------------------------------------------------------------------
+# Signal processing either side of the networks (csrc/dsp.hip)
+# ---------------------------------------------------------------------------------------------------
+def filter3(x, mode):
+    """3-tap NaN-aware filter of a float32 frame sequence: mode 'median' (lower median) or 'mean'
+    (torchcrepe.filter.median / .mean with win_length 3)."""
+    x = x.contiguous().float()
+    out = torch.empty_like(x)
+    _check(x)
+    _call("aicg_filter3", _ptr(x), _ptr(out), x.numel(), {"median": 0, "mean": 1}[mode], _stream(x))
+    return out
+
+
+_filtfilt_plans = {}
+
+
+def _filtfilt_plan(b, a):
+    """Host-side constants of scipy.signal.filtfilt(b, a, .) with default arguments: normalised coefficients, lfilter_zi initial
+    conditions, padlen, and the warm-up length after which a zero-state start is indistinguishable in float64."""
+    key = (tuple(np.asarray(b, np.float64)), tuple(np.asarray(a, np.float64)))
+    if key not in _filtfilt_plans:
+        from scipy.signal import lfilter_zi
+        bb, aa = np.asarray(b, np.float64), np.asarray(a, np.float64)
+        n = max(len(aa), len(bb))
+        bb = np.concatenate([bb, np.zeros(n - len(bb))])
+        aa = np.concatenate([aa, np.zeros(n - len(aa))])
+        zi = np.ascontiguousarray(lfilter_zi(bb, aa), dtype=np.float64)
+        rmax = float(np.max(np.abs(np.roots(aa)))) if n > 1 else 0.0
+        if not rmax < 1.0:
+            raise ValueError("filtfilt: unstable filter (max |pole| = %g)" % rmax)
+        # warm-up: where the envelope of the impulse response has fallen 18 decades (clustered poles -- a Butterworth's -- decay
+        # like n^k r^n, so the pole radius alone under-estimates it)
+        from scipy.signal import lfilter
+        imp = np.zeros(1 << 17)
+        imp[0] = 1.0
+        env = np.maximum.accumulate(np.abs(lfilter(bb, aa, imp))[::-1])[::-1]
+        below = np.nonzero(env < 1e-18 * env[0])[0]
+        if len(below) == 0:
+            raise ValueError("filtfilt: impulse response too long for the block-parallel recurrence")
+        warm = (int(below[0]) + 255) // 256 * 256
+        _filtfilt_plans[key] = (np.ascontiguousarray(bb), np.ascontiguousarray(aa), zi, n - 1, 3 * n, warm)
+    return _filtfilt_plans[key]
+
+
+def filtfilt_f64(x, b, a, block=8192):
+    """scipy.signal.filtfilt(b, a, x) (default odd padding / lfilter_zi) of a float64 device signal, block-parallel."""
+    x = x.contiguous().double()
+    bb, aa, zi, order, padlen, warm = _filtfilt_plan(b, a)
+    n = x.numel()
+    y = torch.empty_like(x)
+    ext = torch.empty(n + 2 * padlen, dtype=torch.float64, device=x.device)
+    mid = torch.empty_like(ext)
+    _check(x)
+    _call("aicg_filtfilt_f64", _ptr(x), _ptr(y), n, bb.ctypes.data, aa.ctypes.data, zi.ctypes.data, order, padlen, int(block),
+          int(warm), _ptr(ext), _ptr(mid), _stream(x))
+    return y
+
+
+_resample_plans = {}
+
+
+def _resample_plan(up, down, n_in, device):
+    """Filter and trimming of scipy.signal.resample_poly(x float32, up, down) (Kaiser-5 windowed sinc, 10 * max(up, down) zero
+    crossings each side), as the polyphase table the kernel reads."""
+    g = math.gcd(int(up), int(down))
+    up, down = int(up) // g, int(down) // g
+    key = (up, down, str(device))
+    if key not in _resample_plans:
+        from scipy.signal import firwin
+        max_rate = max(up, down)
+        half_len = 10 * max_rate
+        h = firwin(2 * half_len + 1, 1.0 / max_rate, window=("kaiser", 5.0)).astype(np.float32)
+        h *= up
+        n_pre_pad = down - half_len % down
+        hpad = np.concatenate([np.zeros(n_pre_pad, np.float32), h])
+        taps = (len(hpad) + up - 1) // up
+        table = np.zeros((up, taps), np.float32)
+        for ph in range(up):
+            col = hpad[ph::up]
+            table[ph, :len(col)] = col
+        _resample_plans[key] = (torch.from_numpy(table).to(device), taps, (half_len + n_pre_pad) // down)
+    table, taps, pre = _resample_plans[key]
+    n_out = n_in * up
+    n_out = n_out // down + bool(n_out % down)
+    return up, down, table, taps, pre, n_out
+
+
+def resample_poly_mono(x, sr_in, sr_out):
+    """(C, N) or (N,) float32 device signal at sr_in -> (n_out,) float32 mono at sr_out: channel mean + polyphase FIR with
+    scipy.signal.resample_poly's filter and trimming."""
+    x = x.float()
+    if x.dim() == 1:
+        x = x.unsqueeze(0)
+    assert x.stride(1) == 1
+    c, n = x.shape
+    up, down, table, taps, pre, n_out = _resample_plan(sr_out, sr_in, n, x.device)
+    y = torch.empty(n_out, dtype=torch.float32, device=x.device)
+    _check(x, table)
+    _call("aicg_resample_poly", _ptr(x), _ptr(y), n, n_out, c, x.stride(0), up, down, _ptr(table), taps, pre, _stream(x))
+    return y
+
+
+def row_sqnorm(v):
+    v = v.contiguous().float()
+    out = torch.empty(v.shape[0], dtype=torch.float32, device=v.device)
+    _check(v)
+    _call("aicg_row_sqnorm", _ptr(v), _ptr(out), v.shape[0], v.shape[1], _stream(v))
+    return out
+
+
+def knn8_update(dots, xnorm, qnorm, col_off, best_d, best_i, merge):
+    """dots (rows, cols) inner products of one column chunk of the index -> running 8 nearest (squared L2, ascending)."""
+    assert dots.dim() == 2 and dots.stride(1) == 1
+    _check(dots, xnorm, qnorm, best_d, best_i)
+    _call("aicg_knn8", _ptr(dots), dots.stride(0), _ptr(xnorm), _ptr(qnorm), dots.shape[0], dots.shape[1], int(col_off),
+          _ptr(best_d), _ptr(best_i), 1 if merge else 0, _stream(dots))
+
+
+def index_mix_(feats, big, best_d, best_i, rate):
+    """feats (rows, dim) <- rate * sum_k w_k big[best_i[k]] + (1 - rate) * feats, w = inverse-square-distance weights."""
+    assert feats.is_contiguous() and big.is_contiguous()
+    _check(feats, big, best_d, best_i)
+    _call("aicg_index_mix", _ptr(feats), _ptr(big), _ptr(best_d), _ptr(best_i), feats.shape[0], feats.shape[1], float(rate),
+          _stream(feats))
+    return feats

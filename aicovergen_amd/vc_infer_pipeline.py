@@ -74,12 +74,47 @@ class VC(object):
         """mangio-crepe (reference :96-137).  The CREPE network is built lazily from torchcrepe's bundled weights, or
         injected as `self.model_crepe[model]` (tests / benchmarks use seeded parameters)."""
         from . import crepe
+        print("Initiating prediction with a crepe_hop_length of: " + str(hop_length))
+        return crepe.mangio_crepe_f0(self._crepe(model), x, p_len, hop_length, dither=dither)
+
+    def _crepe(self, model):
+        from . import crepe
         if not hasattr(self, "model_crepe"):
             self.model_crepe = {}
         if model not in self.model_crepe:
             self.model_crepe[model] = crepe.load_crepe(model, self.device)
-        print("Initiating prediction with a crepe_hop_length of: " + str(hop_length))
-        return crepe.mangio_crepe_f0(self.model_crepe[model], x, p_len, hop_length, dither=dither)
+        return self.model_crepe[model]
+
+    def get_f0_official_crepe_computation(self, x, f0_min, f0_max, model="full", dither=None):
+        """f0_method 'crepe' / 'crepe-tiny' (reference :139-165): torchcrepe.predict at the 10 ms hop with periodicity, 3-frame
+        median of the periodicity, 3-frame mean of f0, unvoiced (periodicity < 0.1) frames zeroed."""
+        from . import crepe
+        return crepe.official_crepe_f0(self._crepe(model), x, self.window, f0_min, f0_max, dither=dither)
+
+    def get_f0_hybrid_computation(self, methods_str, input_audio_path, x, f0_min, f0_max, p_len, filter_radius,
+                                  crepe_hop_length, time_step):
+        """hybrid[m1+m2+...] (reference :175-260): nan-median over the listed estimators on the quantile-normalised signal."""
+        methods = methods_str.split("hybrid")[1].replace("[", "").replace("]", "").split("+")
+        print("Calculating f0 pitch estimations for methods: %s" % str(methods))
+        x = x.astype(np.float32)
+        x = x / np.quantile(np.abs(x), 0.999)
+        stack = []
+        for method in methods:
+            if method in ("crepe", "crepe-tiny"):
+                f0 = self.get_f0_official_crepe_computation(x, f0_min, f0_max, "tiny" if method.endswith("tiny") else "full")[1:]
+            elif method in ("mangio-crepe", "mangio-crepe-tiny"):
+                f0 = self.get_f0_crepe_computation(x, f0_min, f0_max, p_len, crepe_hop_length,
+                                                   "tiny" if method.endswith("tiny") else "full")
+            else:
+                raise NotImplementedError("hybrid f0: method %r needs parselmouth / pyworld (supported inside hybrid[...]: "
+                                          "crepe, crepe-tiny, mangio-crepe, mangio-crepe-tiny)" % method)
+            stack.append(np.asarray(f0, dtype=np.float64))
+        for fc in stack:
+            print(len(fc))
+        print("Calculating hybrid median f0 from the stack of: %s" % str(methods))
+        if len(stack) == 1:
+            return stack[0]
+        return np.nanmedian(stack, axis=0)   # like the reference, estimators of different lengths raise here
 
     def _rmvpe(self):
         if not hasattr(self, "model_rmvpe"):
@@ -94,17 +129,25 @@ class VC(object):
         f0_min, f0_max = 50, 1100
         f0_mel_min = 1127 * np.log(1 + f0_min / 700)
         f0_mel_max = 1127 * np.log(1 + f0_max / 700)
+        def host(a):   # the crepe branches start with host numpy arithmetic (quantile normalisation), like the reference
+            return a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+
         if _raw_f0 is not None:
             f0 = _raw_f0
         elif f0_method == "rmvpe":
             f0 = self._rmvpe().infer_from_audio(x, thred=0.03)
         elif f0_method in ("mangio-crepe", "mangio-crepe-tiny"):
-            f0 = self.get_f0_crepe_computation(x, f0_min, f0_max, p_len, crepe_hop_length,
+            f0 = self.get_f0_crepe_computation(host(x), f0_min, f0_max, p_len, crepe_hop_length,
                                                "tiny" if f0_method.endswith("tiny") else "full")
+        elif f0_method in ("crepe", "crepe-tiny"):
+            f0 = self.get_f0_official_crepe_computation(host(x), f0_min, f0_max, "tiny" if f0_method.endswith("tiny") else "full")
+        elif "hybrid" in f0_method:
+            f0 = self.get_f0_hybrid_computation(f0_method, input_audio_path, host(x), f0_min, f0_max, p_len, filter_radius,
+                                                crepe_hop_length, self.window / self.sr * 1000)
         else:
             raise NotImplementedError(
-                "f0_method %r needs parselmouth / pyworld / torchcrepe filters, which are outside the MI355X hot path "
-                "(supported: rmvpe, mangio-crepe)" % f0_method)
+                "f0_method %r needs parselmouth / pyworld, which are outside the MI355X hot path "
+                "(supported: rmvpe, mangio-crepe[-tiny], crepe[-tiny], hybrid[...] of the crepe methods)" % f0_method)
         tf0 = self.sr // self.window
         f0 = np.asarray(f0, dtype=np.float64)
         factor = pow(2, f0_up_key / 12)
@@ -156,7 +199,10 @@ class VC(object):
                                         output_layer=9 if version == "v1" else 12)
         feats = model.final_proj(logits[0]) if version == "v1" else logits[0]
         feats0 = feats.clone() if use_protect else None
-        if index is not None and big_npy is not None and index_rate != 0:
+        if index is not None and hasattr(index, "mix_") and index_rate != 0:
+            # device retrieval (aicovergen_amd.retrieval.FeatureIndex): exact k = 8 search + inverse-square blend in HBM
+            feats = index.mix_(feats[0].contiguous(), index_rate).unsqueeze(0)
+        elif index is not None and big_npy is not None and index_rate != 0:
             npy = feats[0].cpu().numpy().astype("float32")
             score, ix = index.search(npy, k=8)
             weight = np.square(1 / score)
@@ -188,20 +234,41 @@ class VC(object):
 
     # ---- whole track ----------------------------------------------------------------------------------------------
     def plan(self, audio):
-        """High-pass, cut search and padding (reference :513-534): -> (audio_hp float64, audio_pad, opt_ts, p_len)."""
-        audio = signal.filtfilt(bh, ah, audio)  # zero-phase IIR (float64, sequential recurrence): stays on the host
-        audio_pad = np.pad(audio, (self.window // 2, self.window // 2), mode="reflect")
+        """High-pass, cut search and padding (reference :513-534) -> (audio_hp, audio_pad, opt_ts, p_len); audio_hp / audio_pad are
+        float64 tensors on self.device.  `audio`: the reference's host array, or a float tensor already resident on the device
+        (the opt-in hand-over from the separation stage).
+        The zero-phase Butterworth runs block-parallel on the device (ops.filtfilt_f64; AICG_FILTFILT=host keeps scipy's
+        sequential recurrence on the host): it agrees with scipy.signal.filtfilt to ~5e-8 of the signal peak, which is the
+        rounding-noise floor of this ill-conditioned direct-form filter itself (tests/test_dsp.py compares both against an
+        extended-precision run)."""
+        dev = self.device if ops._lib.backend() != "emu" else torch.device("cpu")
+        if torch.is_tensor(audio):
+            a = audio.detach().to(dev).double().view(-1)
+        else:
+            a = torch.from_numpy(np.ascontiguousarray(audio, dtype=np.float64)).to(dev)
+        if os.environ.get("AICG_FILTFILT", "device") == "host" or a.numel() <= 3 * max(len(ah), len(bh)):
+            audio = torch.from_numpy(np.ascontiguousarray(signal.filtfilt(bh, ah, a.cpu().numpy()))).to(dev)
+        else:
+            audio = ops.filtfilt_f64(a, bh, ah)
+        n = audio.numel()
+
+        def reflect_pad(x, k):   # np.pad(x, (k, k), mode="reflect"): a re-indexing (numpy reflects repeatedly when k >= n)
+            if k < n:
+                return F.pad(x.view(1, 1, -1), (k, k), mode="reflect").view(-1)
+            period = max(2 * (n - 1), 1)
+            i = (torch.arange(-k, n + k, device=x.device) % period)
+            return x[torch.where(i >= n, period - i, i)]
+
         opt_ts = []
-        if audio_pad.shape[0] > self.t_max:
+        if n + self.window > self.t_max:
             # 160-tap box sum in the reference's summation order + first-minimum search, on the device (bit-exact)
-            ap = torch.from_numpy(audio_pad).to(self.device)
-            audio_sum = ops.box_sum_f64(ap, audio.shape[0], self.window)
-            centers = list(range(self.t_center, audio.shape[0], self.t_center))
+            audio_sum = ops.box_sum_f64(reflect_pad(audio, self.window // 2), n, self.window)
+            centers = list(range(self.t_center, n, self.t_center))
             starts = [t - self.t_query for t in centers]
-            lens = [min(t + self.t_query, audio.shape[0]) - (t - self.t_query) for t in centers]
+            lens = [min(t + self.t_query, n) - (t - self.t_query) for t in centers]
             idx = ops.argmin_abs_f64(audio_sum, starts, lens).cpu().numpy()
             opt_ts = [int(s0 + i) for s0, i in zip(starts, idx)]
-        audio_pad = np.pad(audio, (self.t_pad, self.t_pad), mode="reflect")
+        audio_pad = reflect_pad(audio, self.t_pad)
         return audio, audio_pad, opt_ts, audio_pad.shape[0] // self.window
 
     def chunk_bounds(self, audio_pad, opt_ts):
@@ -234,9 +301,13 @@ class VC(object):
         index = big_npy = None
         if file_index != "" and os.path.exists(file_index) and index_rate != 0:
             try:
-                import faiss
-                index = faiss.read_index(file_index)
-                big_npy = index.reconstruct_n(0, index.ntotal)
+                if os.environ.get("AICG_GPU_KNN", "1") != "0":
+                    from . import retrieval
+                    index = retrieval.load_index(file_index, self.device)   # vectors in HBM, search + mix on the device
+                else:
+                    import faiss   # the reference's host path: faiss search per chunk
+                    index = faiss.read_index(file_index)
+                    big_npy = index.reconstruct_n(0, index.ntotal)
             except Exception:
                 traceback.print_exc()
                 index = big_npy = None
@@ -282,7 +353,7 @@ class VC(object):
                 side = self._f0_stream = torch.cuda.Stream(device=self.device)
             # one upload of the padded track: a pageable host->device copy on the default stream waits for the whole device,
             # side stream included, so the chunk loop below must not issue any
-            pad_dev = torch.from_numpy(np.ascontiguousarray(audio_pad)).to(self.device).float()
+            pad_dev = audio_pad.float()
             side.wait_stream(main)
             tf0 = ttime()
             with torch.cuda.stream(side):
@@ -337,13 +408,13 @@ class VC(object):
             # optional output resampling (rvc_infer passes resample_sr=0): host fallback, not on the hot path
             a = audio_opt.cpu().numpy()
             if rms_mix_rate != 1:
-                a = change_rms(audio, 16000, a, tgt_sr, rms_mix_rate)
+                a = change_rms(audio.cpu().numpy(), 16000, a, tgt_sr, rms_mix_rate)
             from scipy.signal import resample_poly
             g = np.gcd(int(tgt_sr), int(resample_sr))
             audio_opt = torch.from_numpy(resample_poly(a, resample_sr // g, tgt_sr // g).astype(np.float32)).to(self.device)
         elif rms_mix_rate != 1:
             # change_rms on the device: frame RMS envelopes (1 s frames, 0.5 s hop), linear interpolation, power mix
-            rms1 = ops.frame_rms(torch.from_numpy(np.ascontiguousarray(audio)).to(self.device), 16000 // 2 * 2, 16000 // 2)
+            rms1 = ops.frame_rms(audio, 16000 // 2 * 2, 16000 // 2)
             rms2 = ops.frame_rms(audio_opt, tgt_sr // 2 * 2, tgt_sr // 2)
             ops.rms_mix_(audio_opt, rms1, rms2, rms_mix_rate)
         audio_max = float(ops.absmax(audio_opt).item()) / 0.99

@@ -257,6 +257,42 @@ int aicg_affine_maxpool2(const float* x, const float* scale, const float* shift,
 int aicg_crepe_viterbi(const float* probs, const int* seq_len, float* logp_scratch, uint16_t* ptr_scratch,
                        int64_t* bins_out, int n_seq, int n_bins, int max_steps, int bin_lo, int bin_hi, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Signal processing either side of the networks (csrc/dsp.hip)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* 3-tap filter of a frame sequence over its in-range, non-NaN neighbours: mode 0 = lower median, 1 = mean (a mean of exactly 0 and
+ * an empty window give NaN).  torchcrepe.filter.median(pd, 3) / .mean(f0, 3) of the 'crepe' / 'crepe-tiny' f0 methods
+ * (src/vc_infer_pipeline.py:160-161). */
+int aicg_filter3(const float* x, float* out, int64_t n, int mode, void* stream);
+
+/* scipy.signal.filtfilt(b, a, x) with its defaults (odd extension by padlen samples, lfilter_zi initial conditions), float64:
+ * the 48 Hz Butterworth high-pass of VC.pipeline (src/vc_infer_pipeline.py:22,513).  b, a (order + 1 entries) and zi (order
+ * entries, scipy.signal.lfilter_zi) are HOST arrays; x, y (n samples) and the scratch ext, mid (n + 2 padlen samples each) are
+ * device arrays.  The recurrence runs block-parallel: each thread re-runs `warm` samples in front of its `block` outputs from a
+ * zero state (the caller picks warm so that max|pole|^warm is below float64 rounding). */
+int aicg_filtfilt_f64(const double* x, double* y, int64_t n, const double* b, const double* a, const double* zi, int order,
+                      int padlen, int block, int warm, double* ext, double* mid, void* stream);
+
+/* y[i] = sum_m h[(i + pre) * down - m * up] * mean_c x[c][m]: scipy.signal.resample_poly / upfirdn with the filter given as the
+ * polyphase table hp[phase][tap] = h[phase + tap * up] (taps per phase, zero padded), plus the channel mean of a
+ * (n_channels, n_in) input with channel stride x_sc.  The opt-in device hand-over of the separated vocals to the RVC stage
+ * (44.1 kHz stereo -> 16 kHz mono), which the reference does through a PCM-16 WAV and ffmpeg (src/mdx.py:273,280,
+ * src/my_utils.py:14-16). */
+int aicg_resample_poly(const float* x, float* y, int64_t n_in, int64_t n_out, int n_channels, int64_t x_sc, int up, int down,
+                       const float* hp, int taps, int64_t pre, void* stream);
+
+/* Retrieval mix of VC.vc (src/vc_infer_pipeline.py:409-431: index.search(npy, k=8), inverse-square weights, blend):
+ * aicg_row_sqnorm: |v_r|^2 of a (rows, dim) matrix;
+ * aicg_knn8: exact 8 nearest neighbours by squared L2 distance from inner products dots[r][c] (row stride ld) of one column
+ *   chunk [col_off, col_off + cols) of the index, merged into best_d / best_i (rows x 8, ascending) when merge != 0;
+ * aicg_index_mix: feats = rate * sum_k w_k big[best_i[k]] + (1 - rate) * feats with w = (1/d)^2 / sum (1/d)^2. */
+int aicg_row_sqnorm(const float* v, float* out, int64_t rows, int dim, void* stream);
+int aicg_knn8(const float* dots, int64_t ld, const float* xnorm, const float* qnorm, int rows, int cols, int64_t col_off,
+              float* best_d, int64_t* best_i, int merge, void* stream);
+int aicg_index_mix(float* feats, const float* big, const float* best_d, const int64_t* best_i, int rows, int dim, float rate,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -56,3 +56,17 @@ def song_like(seconds, sr=44100, seed=1234):
     right = voice + np.concatenate([np.zeros(d), acc[:-d]]) + 10 ** (-60 / 20) * rng.standard_normal(n)
     out = np.stack([left, right])
     return (0.95 * out / np.abs(out).max()).astype(np.float32)
+
+
+def fake_crepe_tracks(n, seed):
+    """Deterministic stand-in for torchcrepe.predict's outputs on n frames: (pitch float32 with some sub-0.001 entries, which the
+    reference gates to NaN; periodicity float32 with stretches below the 0.1 voicing gate).  Used where the code AROUND the
+    network is under test (tests/golden/make_crepe_golden.py and tests/test_crepe.py share it)."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n)
+    pitch = (180.0 + 60.0 * np.sin(t / 17.0) + rng.normal(0.0, 3.0, n)).astype(np.float32)
+    pitch[rng.random(n) < 0.05] = 0.0005
+    pd = rng.random(n).astype(np.float32)
+    for s in range(0, n, 53):
+        pd[s: s + 9] *= 0.05
+    return pitch, pd

@@ -97,3 +97,47 @@ def test_crepe_full_matches_oracle():
     op, ob, opost = ocr.predict(sd, x, hop, batch_size=2 * hop, dither=d)
     assert rel_rms(post, torch.from_numpy(opost)) < 1e-4
     assert (bins.cpu().numpy() == ob).mean() > 0.98
+
+
+def test_crepe_post_processing_matches_reference_golden(dev, monkeypatch):
+    """SURVEY 8a row a13, pinned against the REFERENCE's own code: tests/golden/crepe_post_ref.npz holds the outputs of
+    /root/reference/src/vc_infer_pipeline.py's get_f0_crepe_computation / get_f0_official_crepe_computation /
+    get_f0_hybrid_computation / get_f0 with torchcrepe.predict replaced by synthetic.inputs.fake_crepe_tracks
+    (tests/golden/make_crepe_golden.py).  Here the same tracks replace crepe.predict, so everything around the network -- the
+    quantile normalisation, the < 0.001 -> NaN gate, np.interp to p_len, the 3-frame median / mean kernels, the periodicity
+    gate, f0[1:], np.nanmedian, the coarse-bin quantiser -- is compared with what the reference computed."""
+    import os
+    from aicovergen_amd.vc_infer_pipeline import VC
+    from synthetic.inputs import fake_crepe_tracks
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "crepe_post_ref.npz"))
+
+    def fake_predict(net, audio, hop, fmin=50.0, fmax=1100.0, batch_size=None, dither=None, frame_batch=2048):
+        n = 1 + len(audio) // hop
+        pitch, pd = fake_crepe_tracks(n, 1000 + hop)
+        post = torch.zeros((n, 360))
+        post[:, 5] = torch.from_numpy(pd)
+        return dev.t(torch.from_numpy(pitch)), dev.t(torch.full((n,), 5, dtype=torch.int64)), dev.t(post)
+
+    monkeypatch.setattr(crepe, "predict", fake_predict)
+
+    class Cfg:
+        x_pad, x_query, x_center, x_max, is_half = 1, 1, 1, 2, False
+        device = dev.device
+    vc = VC(40000, Cfg())
+    vc.model_crepe = {"full": None, "tiny": None}
+    audio = vocal_like(float(g["seconds"][0]), 16000, int(g["seed"][0])).astype(np.float64)
+    audio[9000:14000] *= 0.002
+    p_len = int(g["p_len"][0])
+    for hop, key in ((128, "mangio_hop128"), (160, "mangio_hop160")):
+        got = vc.get_f0_crepe_computation(audio.copy(), 50, 1100, p_len, hop, "full")
+        assert np.allclose(got, g[key], rtol=1e-6, atol=1e-6), key
+    off = vc.get_f0_official_crepe_computation(audio.copy(), 50, 1100, "full")
+    assert off.shape == g["official"].shape and np.array_equal(off == 0, g["official"] == 0)
+    assert np.allclose(off, g["official"], rtol=1e-6, atol=1e-6)
+    hyb = vc.get_f0_hybrid_computation("hybrid[mangio-crepe+crepe]", "x.wav", audio.copy(), 50, 1100, p_len, 3, 160, 10.0)
+    assert np.allclose(hyb, g["hybrid"], rtol=1e-6, atol=1e-6)
+    coarse, f0 = vc.get_f0("x.wav", audio.copy(), p_len, 2, "crepe", 3, 128)
+    assert np.allclose(f0, g["getf0_f0"], rtol=1e-6, atol=1e-6)
+    assert (coarse != g["getf0_coarse"]).mean() < 0.01          # a bin can flip where f0 * 2^(2/12) differs in the last ulp
+    with pytest.raises(NotImplementedError):
+        vc.get_f0("x.wav", audio.copy(), p_len, 0, "hybrid[pm+crepe]", 3, 128)
