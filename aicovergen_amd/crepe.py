@@ -69,18 +69,26 @@ def load_crepe(model, device):
     return Crepe(torch.load(path, map_location="cpu"), device)
 
 
-def predict(net, audio, hop, fmin=50.0, fmax=1100.0, batch_size=None, dither=None, frame_batch=2048):
-    """torchcrepe.predict for a 16 kHz (N,) waveform on net.device -> (pitch float32 (n_frames,), bins int64).
-    `dither` replaces torchcrepe's random triangular dither of the bin centres (None draws it from torch's RNG)."""
+def predict(net, audio, hop, fmin=50.0, fmax=1100.0, batch_size=None, dither=None, frame_batch=2048, group=None):
+    """torchcrepe.predict for a 16 kHz (N,) waveform on net.device -> (pitch float32 (n_frames,), bins int64, posteriors).
+    `dither` replaces torchcrepe's random triangular dither of the bin centres (None draws it from torch's RNG).
+    `group`: the frames are independent up to the Viterbi pass, so the ranks of a torch.distributed group each run the network
+    on a contiguous slice of them and all-gather the 360-bin posteriors; the decode then runs identically on
+    every rank."""
+    from . import dist as adist
     dev = net.device
     a = torch.as_tensor(audio).float().to(dev).view(-1)
     total = 1 + a.numel() // hop
     ap = F.pad(a, (WINDOW // 2, WINDOW // 2))
-    post = torch.empty((total, PITCH_BINS), dtype=torch.float32, device=dev)
-    for i in range(0, total, frame_batch):
-        n = min(frame_batch, total - i)
+    rank, world = adist.world(group)
+    per = (total + world - 1) // world
+    f0, f1 = min(rank * per, total), min((rank + 1) * per, total)
+    mine = torch.zeros((per, PITCH_BINS), dtype=torch.float32, device=dev)
+    for i in range(f0, f1, frame_batch):
+        n = min(frame_batch, f1 - i)
         fr = ap[i * hop:].unfold(0, WINDOW, hop)[:n].contiguous()          # frame extraction (re-indexing)
-        post[i:i + n] = net(ops.frame_normalize(fr))
+        mine[i - f0:i - f0 + n] = net(ops.frame_normalize(fr))
+    post = adist.all_gather_equal(mine, group)[:total]
     batch_size = batch_size or total
     n_seq = (total + batch_size - 1) // batch_size
     probs = torch.zeros((n_seq, PITCH_BINS, batch_size), dtype=torch.float32, device=dev)
@@ -101,11 +109,11 @@ def predict(net, audio, hop, fmin=50.0, fmax=1100.0, batch_size=None, dither=Non
     return (10 * 2 ** (cents / 1200)), bins, post
 
 
-def mangio_crepe_f0(net, x, p_len, hop, dither=None):
+def mangio_crepe_f0(net, x, p_len, hop, dither=None, group=None):
     """VC.get_f0_crepe_computation (reference src/vc_infer_pipeline.py:96-137)."""
     x = x.astype(np.float32)
     x = x / np.quantile(np.abs(x), 0.999)
-    pitch, bins, post = predict(net, x, hop, 50.0, 1100.0, batch_size=hop * 2, dither=dither)
+    pitch, bins, post = predict(net, x, hop, 50.0, 1100.0, batch_size=hop * 2, dither=dither, group=group)
     p_len = p_len or x.shape[0] // hop
     source = pitch.cpu().float().numpy()
     source[source < 0.001] = np.nan
@@ -113,14 +121,14 @@ def mangio_crepe_f0(net, x, p_len, hop, dither=None):
     return np.nan_to_num(target)
 
 
-def official_crepe_f0(net, x, hop, fmin=50.0, fmax=1100.0, dither=None):
+def official_crepe_f0(net, x, hop, fmin=50.0, fmax=1100.0, dither=None, group=None):
     """VC.get_f0_official_crepe_computation (reference src/vc_infer_pipeline.py:139-165):
     f0, pd = torchcrepe.predict(audio, 16000, hop, fmin, fmax, model, batch_size=512, return_periodicity=True);
     pd = torchcrepe.filter.median(pd, 3); f0 = torchcrepe.filter.mean(f0, 3); f0[pd < 0.1] = 0.
     The periodicity is the posterior at the Viterbi-decoded bin (torchcrepe.core.periodicity); both 3-frame filters run in
     ops.filter3 (wave-shuffle neighbours)."""
     x = np.asarray(x, dtype=np.float32)
-    pitch, bins, post = predict(net, x, hop, fmin, fmax, batch_size=512, dither=dither)
+    pitch, bins, post = predict(net, x, hop, fmin, fmax, batch_size=512, dither=dither, group=group)
     pd = post.gather(1, bins.view(-1, 1)).view(-1)
     pd = ops.filter3(pd, "median")
     f0 = ops.filter3(pitch, "mean")

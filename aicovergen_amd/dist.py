@@ -5,7 +5,10 @@ parallel over fixed-size work items, so the only collective is the join:
   * MDX: the flattened (segment, window) list is cut into `world` contiguous slices; each rank separates its slice
     and one all_gather of equal-size (per, 2, gen) blocks rebuilds the window list on every rank (30-min stereo
     track: 635 MB total, 79 MB per peer link -- bandwidth-trivial on 7 x 153 GB/s xGMI links);
-  * RVC: `vc()` chunks are round-robined over ranks after f0 / cut points are computed once and broadcast.
+  * RVC: `vc()` chunks are round-robined over ranks and joined by a length exchange + padded all_gather.  The cut search and the
+    RMVPE f0 of the whole track are computed redundantly on every rank: both are deterministic, the cut search is a few
+    milliseconds, and RMVPE's BiGRU is one sequential recurrence over the track that no rank can shorten (a broadcast from one
+    rank would leave the others idle for the same time).  CREPE's per-frame network is sharded over the ranks (crepe.predict).
 
 With world_size == 1 (or no initialised process group) every function degenerates to the single-GPU path, so the
 same code is exercised by the 1-GPU tests.
@@ -28,15 +31,6 @@ def all_gather_equal(block, group=None):
     outs = [torch.empty_like(block) for _ in range(ws)]
     td.all_gather(outs, block.contiguous(), group=group)
     return torch.cat(outs, dim=0)
-
-
-def broadcast_tensors(tensors, src=0, group=None):
-    rank, ws = world(group)
-    if ws == 1:
-        return tensors
-    for t in tensors:
-        td.broadcast(t, src=src, group=group)
-    return tensors
 
 
 def mdx_separate(mdx_sess, wave, denoise, m_threads=2, group=None):

@@ -75,7 +75,7 @@ class VC(object):
         injected as `self.model_crepe[model]` (tests / benchmarks use seeded parameters)."""
         from . import crepe
         print("Initiating prediction with a crepe_hop_length of: " + str(hop_length))
-        return crepe.mangio_crepe_f0(self._crepe(model), x, p_len, hop_length, dither=dither)
+        return crepe.mangio_crepe_f0(self._crepe(model), x, p_len, hop_length, dither=dither, group=getattr(self, "_group", None))
 
     def _crepe(self, model):
         from . import crepe
@@ -89,7 +89,8 @@ class VC(object):
         """f0_method 'crepe' / 'crepe-tiny' (reference :139-165): torchcrepe.predict at the 10 ms hop with periodicity, 3-frame
         median of the periodicity, 3-frame mean of f0, unvoiced (periodicity < 0.1) frames zeroed."""
         from . import crepe
-        return crepe.official_crepe_f0(self._crepe(model), x, self.window, f0_min, f0_max, dither=dither)
+        return crepe.official_crepe_f0(self._crepe(model), x, self.window, f0_min, f0_max, dither=dither,
+                                       group=getattr(self, "_group", None))
 
     def get_f0_hybrid_computation(self, methods_str, input_audio_path, x, f0_min, f0_max, p_len, filter_radius,
                                   crepe_hop_length, time_step):
@@ -311,6 +312,7 @@ class VC(object):
             except Exception:
                 traceback.print_exc()
                 index = big_npy = None
+        self._group = group   # the crepe f0 methods shard their frames over it
         tp0 = ttime()
         audio, audio_pad, opt_ts, p_len = self.plan(audio)
         t1 = ttime()

@@ -78,7 +78,7 @@ def test_c1_pipeline_vs_reference_golden():
     n = min(len(coarse), len(gold["coarse"]))
     bad = np.nonzero(coarse[:n] != gold["coarse"][:n])[0]
     r = vc.model_rmvpe
-    mel = r.mel_extractor(torch.from_numpy(audio_pad).float()[None].cuda(), center=True)
+    mel = r.mel_extractor(audio_pad.float()[None].cuda(), center=True)
     sal = r.mel2hidden(mel)[0].cpu().numpy()
     for t, m in zip(bad, _margins(sal, bad)):
         print("  frame %d: bin %d vs reference %d, f0 %.4f vs %.4f Hz, salience top1-top2 %.3e"

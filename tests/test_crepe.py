@@ -111,7 +111,7 @@ def test_crepe_post_processing_matches_reference_golden(dev, monkeypatch):
     from synthetic.inputs import fake_crepe_tracks
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "crepe_post_ref.npz"))
 
-    def fake_predict(net, audio, hop, fmin=50.0, fmax=1100.0, batch_size=None, dither=None, frame_batch=2048):
+    def fake_predict(net, audio, hop, fmin=50.0, fmax=1100.0, batch_size=None, dither=None, frame_batch=2048, group=None):
         n = 1 + len(audio) // hop
         pitch, pd = fake_crepe_tracks(n, 1000 + hop)
         post = torch.zeros((n, 360))

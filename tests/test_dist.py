@@ -68,6 +68,75 @@ def test_two_rank_sharding_matches_single_process():
     assert np.array_equal(out, ref_out)
 
 
+def _worker3(rank, world, port, q):
+    """3 ranks: MDX with an uneven window split (5 windows over 3 ranks: 2 + 2 + 1), an RVC run with TWO chunks (rank 2 idles
+    in the chunk loop but takes part in every collective) and f0_method 'mangio-crepe' with its frames sharded 3 ways."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["AICG_EMU_THREADS"] = "2"
+    torch.set_num_threads(2)
+    import conftest
+    conftest._bind("emu")
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = _three_rank_case(td.group.WORLD)
+        if rank == 0:
+            q.put(res)
+    finally:
+        td.destroy_process_group()
+
+
+def _three_rank_case(group):
+    import conftest
+    from aicovergen_amd import crepe, dist as adist
+    from aicovergen_amd.mdx import MDX, MDXModel
+    from synthetic import weights
+    from synthetic.inputs import song_like, vocal_like
+    import test_pipeline as tp
+    cfg = weights.MDX_TINY
+    model = MDXModel("cpu", cfg["dim_f"], cfg["dim_t"], cfg["n_fft"], hop=64)
+    sess = MDX(None, model, state_dict=weights.mdx_state_dict(cfg, 1234))
+    wave = torch.from_numpy(song_like(0.2, 44100, seed=3)[:, :3900])
+    _, meta = sess.separate(wave, True, 1, shard=(0, 1))
+    sep = adist.mdx_separate(sess, wave, True, 1, group).numpy()
+    nets = weights.small_model_set(1234)
+    dev = conftest.Dev("emu")
+    vc, hub, net_g, tgt_sr = tp.build(dev, nets, (1, 1, 1, 2))
+    vc.model_crepe = {"full": crepe.Crepe(weights.crepe_state_dict(weights.CREPE_MICRO, 5), "cpu")}
+    crepe.DITHER = lambda n: torch.zeros(n)
+    audio = vocal_like(1.995, 16000, 1240)
+    outs = []
+    for method in ("rmvpe", "mangio-crepe"):
+        out = vc.pipeline(hub, net_g, 0, audio, "x.wav", [0, 0, 0], 0, method, "", 0.5, 1, 3, tgt_sr, 0, 0.25, "v2", 0.33, 64,
+                          noise_fn=tp.noise_fn_for(nets), group=group)
+        outs.append(out)
+    _, audio_pad, opt_ts, _ = vc.plan(audio)
+    return sep, outs, len(meta["jobs"]), len(vc.chunk_bounds(audio_pad, opt_ts))
+
+
+@pytest.mark.timeout(900)
+def test_three_rank_uneven_sharding_matches_single_process():
+    import conftest
+    conftest._bind("emu")
+    ref_sep, ref_outs, n_windows, n_chunks = _three_rank_case(None)
+    assert n_windows % 3 != 0 and n_chunks == 2          # an uneven window split and fewer chunks than ranks
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30100 + (os.getpid() % 500)
+    procs = [ctx.Process(target=_worker3, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    sep, outs, _, _ = q.get(timeout=800)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert np.array_equal(sep, ref_sep)
+    for o, r in zip(outs, ref_outs):
+        assert np.array_equal(o, r)
+
+
 def test_mdx_shards_cover_all_windows_once():
     import conftest
     conftest._bind("emu")
