@@ -814,3 +814,64 @@ def index_mix_(feats, big, best_d, best_i, rate):
     _call("aicg_index_mix", _ptr(feats), _ptr(big), _ptr(best_d), _ptr(best_i), feats.shape[0], feats.shape[1], float(rate),
           _stream(feats))
     return feats
+
+
+# ---------------------------------------------------------------------------------------------------
+# Optional per-stage accounting for bench.py's `stages` list (HIP events on the launch stream around the wrapped ops)
+# ---------------------------------------------------------------------------------------------------
+class StageProfile:
+    """name -> launches, algorithmic flops / bytes, HIP-event time.  Enabled with `ops.stage_profile = StageProfile()`."""
+
+    def __init__(self):
+        self.rec = {}
+
+    def add(self, name, e0, e1, flops, nbytes):
+        r = self.rec.setdefault(name, {"events": [], "flops": 0.0, "bytes": 0.0, "launches": 0})
+        r["events"].append((e0, e1))
+        r["flops"] += flops
+        r["bytes"] += nbytes
+        r["launches"] += 1
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, r in self.rec.items():
+            ms = sum(a.elapsed_time(b) for a, b in r["events"])
+            out[name] = {"launches": r["launches"], "ms": ms, "flops": r["flops"], "bytes": r["bytes"]}
+        return out
+
+
+stage_profile = None
+
+
+def _staged(name, fn, work):
+    """work(args, kwargs, result) -> (algorithmic flops, algorithmic HBM bytes) of one call."""
+    def wrapped(*a, **k):
+        prof = stage_profile
+        t = a[0] if a and torch.is_tensor(a[0]) else None
+        if prof is None or t is None or not t.is_cuda:
+            return fn(*a, **k)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        r = fn(*a, **k)
+        e1.record()
+        fl, by = work(a, k, r)
+        prof.add(name, e0, e1, fl, by)
+        return r
+    wrapped.__name__, wrapped.__doc__ = fn.__name__, fn.__doc__
+    return wrapped
+
+
+def _numel(*ts):
+    return float(sum(t.numel() for t in ts if t is not None))
+
+
+stft = _staged("stft", stft, lambda a, k, r: (0.0, 4.0 * _numel(a[0], r)))
+istft = _staged("istft", istft, lambda a, k, r: (0.0, 4.0 * _numel(a[0], r)))
+linear_last = _staged("tdf_gemm_nt", linear_last, lambda a, k, r: (2.0 * r.numel() * a[1].shape[1],
+                                                                   4.0 * _numel(a[0], a[1], r, k.get("res"))))
+attention = _staged("attention", attention, lambda a, k, r: (4.0 * a[0].numel() * a[0].shape[1],      # 4 T^2 D per head
+                                                             4.0 * _numel(a[0], a[1], a[2], r)))
+sine_source = _staged("sine_source", sine_source, lambda a, k, r: (0.0, 4.0 * _numel(a[0], a[1], r)))
+layernorm_ct = _staged("layernorm", layernorm_ct, lambda a, k, r: (0.0, 4.0 * _numel(a[0], k.get("res"), r)))
+rownorm_act = _staged("groupnorm_gelu", rownorm_act, lambda a, k, r: (0.0, 4.0 * _numel(a[0], r)))

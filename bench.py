@@ -1,20 +1,27 @@
 #!/usr/bin/env python
 """Headline benchmark: real-time factor (audio-seconds / wall-seconds) of MDX-Net separation + RVC voice conversion
-on a 4-minute 44.1 kHz stereo track per GPU (BASELINE.json metric, config C3 of SURVEY 8d).
+on a 4-minute 44.1 kHz stereo track per GPU (BASELINE.json metric; configs of SURVEY 8d).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config C3]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One "step" = one pass of the hot path over one synthetic track of 240 s x N:
-  (1) MDX: peak-normalised S44 stereo wave (resident in HBM) -> framed STFT -> TFC-TDF U-Net (Voc_FT-class geometry:
-      dim_f 3072, dim_t 256, n_fft 7680, denoise on => 2 network passes per window) -> iSTFT -> window join;
-  (2) RVC: S16 mono wave -> VC.pipeline (48 Hz high-pass, cut search, RMVPE f0 on the whole track, per chunk:
-      HuBERT-base -> nearest x2 + protect -> SynthesizerTrnMs768NSFsid 40 kHz) -> int16.
-At N > 1 the window list (MDX) and the chunk list (RVC) are sharded across ranks and joined by RCCL all-gathers
-(weak scaling: per-GPU audio is fixed at 240 s).  All network parameters are seeded random tensors of the real
-architectures (no checkpoints exist offline); data is synthetic.  Compute dtype fp32 (MFMA f32).
+--config  C3 (default, the headline): MDX (1 model) -> separated vocals -> 44.1 kHz stereo to 16 kHz mono on the device ->
+              VC.pipeline with rmvpe f0.  One "step" = one synthetic track of 240 s x N through both stages.
+          C2: the MDX stage alone.          C4: C3 with f0_method = mangio-crepe (hop 128).
+          C5: one 1800 s track in total, sharded over the N ranks (strong scaling).
+--mdx-models 3  runs main.py's chain of three separations (Voc_FT -> KARA-class -> Reverb_HQ-class geometries) instead of one.
+
+MDX: peak-normalised stereo wave resident in HBM -> framed STFT -> TFC-TDF U-Net (Voc_FT-class geometry: dim_f 3072, dim_t 256,
+n_fft 7680, denoise on => 2 network passes per window) -> iSTFT -> window join.  RVC: 48 Hz zero-phase high-pass, cut search,
+f0 on the whole track, per chunk HuBERT-base -> nearest x2 + protect -> SynthesizerTrnMs768NSFsid 40 kHz, RMS mix, int16.
+The hand-over between the stages is the opt-in device path (aicg_resample_poly, scipy.signal.resample_poly semantics); the
+reference goes through a PCM-16 WAV and ffmpeg (not installed here).  Model loading, file I/O and main.py's mixing / effects
+are outside the timed region.  At N > 1 the window list (MDX) and the chunk list (RVC) are sharded across ranks and joined by
+RCCL all-gathers.  All network parameters are seeded random tensors of the real architectures (no checkpoints exist offline);
+data is synthetic.  Compute dtype fp32 (MFMA f32).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -27,9 +34,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 TRACK_S = 240.0
+PEAK_F32_MFMA = 157.3   # TFLOP/s, MI355X_MICROARCH.md
+PEAK_HBM = 8000.0       # GB/s spec (6290 measured float4 copy)
 
 
-def build_models(device):
+def build_models(device, config, n_mdx):
     from aicovergen_amd.hubert import HubertModel
     from aicovergen_amd.infer_pack.models import SynthesizerTrnMs768NSFsid
     from aicovergen_amd.mdx import MDX, MDXModel
@@ -37,38 +46,55 @@ def build_models(device):
     from aicovergen_amd.rvc import Config
     from aicovergen_amd.vc_infer_pipeline import VC
     from synthetic import weights
-    mcfg = weights.MDX_VOC_FT
-    model = MDXModel(device, mcfg["dim_f"], mcfg["dim_t"], mcfg["n_fft"], stem_name="Vocals", compensation=1.021)
-    mdx = MDX(None, model, state_dict=weights.mdx_state_dict(mcfg, 1234))
+    mdxs = []
+    for i, mcfg in enumerate([weights.MDX_VOC_FT, weights.MDX_KARA2, weights.MDX_REVERB_HQ][:n_mdx]):
+        model = MDXModel(device, mcfg["dim_f"], mcfg["dim_t"], mcfg["n_fft"], stem_name="Vocals", compensation=1.021)
+        mdxs.append(MDX(None, model, state_dict=weights.mdx_state_dict(mcfg, 1234 + i)))
+    if config == "C2":
+        return mdxs, None, None, None
     cfg = Config(str(device), True)  # what main.py selects: the "6G" fp16 preset x = (3, 10, 60, 65)
     cfg.device = device
     vc = VC(40000, cfg)
     hub = HubertModel(weights.hubert_state_dict(weights.HUBERT_BASE, 1234), weights.HUBERT_BASE).to(device)
-    vc.model_rmvpe = RMVPE(None, False, device, state_dict=weights.rmvpe_state_dict(weights.RMVPE_FULL, 1235))
+    if config == "C4":
+        from aicovergen_amd.crepe import Crepe
+        vc.model_crepe = {"full": Crepe(weights.crepe_state_dict(weights.CREPE_FULL, 1237), device)}
+    else:
+        vc.model_rmvpe = RMVPE(None, False, device, state_dict=weights.rmvpe_state_dict(weights.RMVPE_FULL, 1235))
     net_g = SynthesizerTrnMs768NSFsid(*weights.SYNTH_CFG_40K_V2, is_half=False)
     del net_g.enc_q
     net_g.load_state_dict(weights.synth_state_dict(weights.SYNTH_CFG_40K_V2, 1236), strict=False)
     net_g.eval().to(device)
-    return mdx, vc, hub, net_g
+    return mdxs, vc, hub, net_g
 
 
-def one_step(mdx, vc, hub, net_g, wave44_dev, wave16, group):
+def one_step(config, mdxs, vc, hub, net_g, wave44_dev, group):
     from aicovergen_amd import dist as adist
+    from aicovergen_amd import ops
     t0 = time.perf_counter()
-    sep = adist.mdx_separate(mdx, wave44_dev, True, 2, group)
+    sep = wave44_dev
+    for m in mdxs:   # main.py feeds each separation the previous one's stem
+        sep = adist.mdx_separate(m, sep, True, 2, group)
     torch.cuda.synchronize()  # stage boundary (the reference writes the stems to disk here)
     mdx_s = time.perf_counter() - t0
+    if config == "C2":
+        return sep, None, [0, 0, 0], {"mdx_s": mdx_s}
+    t1 = time.perf_counter()
+    wave16 = ops.resample_poly_mono(sep, 44100, 16000)      # stereo 44.1 kHz -> mono 16 kHz, stays in HBM
+    torch.cuda.synchronize()
     times = [0, 0, 0]
-    out = vc.pipeline(hub, net_g, 0, wave16, "synthetic.wav", times, 0, "rmvpe", "", 0.5, 1, 3, 40000, 0, 0.25, "v2", 0.33,
-                      128, group=group, noise_seed=1234)
-    return sep, out, times, dict(vc.last_profile, mdx_s=mdx_s)
+    method = "mangio-crepe" if config == "C4" else "rmvpe"
+    out = vc.pipeline(hub, net_g, 0, wave16, "synthetic.wav", times, 0, method, "", 0.5, 1, 3, 40000, 0, 0.25, "v2", 0.33, 128,
+                      group=group, noise_seed=1234)
+    return sep, out, times, dict(vc.last_profile, mdx_s=mdx_s, resample_s=time.perf_counter() - t1 - sum(
+        vc.last_profile[k] for k in ("plan_s", "f0_s", "chunks_s", "post_s")))
 
 
-def cpu_baseline(seconds_rvc=4.0):
-    """The oracle (CPU restatement of the reference, "port") timed on this box's host cores on a bounded sample:
-    one MDX window pair (denoise => 2 U-Net passes, 5.57 s of audio) + the RVC pipeline on `seconds_rvc` s.
-    Threads: min(host cores, 16) -- torch's intra-op pool degrades badly beyond that on these layer sizes (256
-    threads measured 100x slower than 16 on the GPU box's 256-core EPYC), so that is what is used and reported."""
+def cpu_baseline():
+    """The oracle (CPU restatement of the reference, "port") timed on this box's host cores on a bounded sample: one MDX window pair
+    (denoise => 2 U-Net passes, 5.57 s of audio) + the RVC pipeline on 30 s (BASELINE C1's length: one 576 000-sample chunk, so
+    the chunk padding is amortised as in a long track).  Threads: min(host cores, 16) -- torch's intra-op pool degrades badly
+    beyond that on these layer sizes (256 threads measured 100x slower than 16 on the GPU box's EPYC)."""
     from oracle import mdxnet
     from oracle import pipeline as opipe
     from synthetic import weights
@@ -87,26 +113,49 @@ def cpu_baseline(seconds_rvc=4.0):
     mdx_cost = (time.time() - t0) / gen_s          # CPU seconds per audio second
     nets = weights.full_model_set(1234)
     geo = opipe.Geometry(40000, 3, 10, 60, 65)
+    seconds_rvc = 30.0
     a = vocal_like(seconds_rvc, 16000, 2)
     t0 = time.time()
     opipe.vc_pipeline(nets, geo, a, tgt_sr=40000)
     rvc_cost = (time.time() - t0) / seconds_rvc
-    return {"value": 1.0 / (mdx_cost + rvc_cost), "unit": "x real-time", "cores": cores, "kind": "port",
-            "sample": "1 MDX window pair (5.57 s, denoise) + VC.pipeline (rmvpe) on %.0f s; CPU seconds per audio second: %.2f (MDX) + %.2f (RVC)"
-                      % (seconds_rvc, mdx_cost, rvc_cost)}
+    return {"value": 1.0 / (mdx_cost + rvc_cost), "unit": "x real-time", "cores": cores, "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": "oracle port: 1 MDX window pair (5.57 s, denoise) + VC.pipeline (rmvpe) on %.0f s; CPU seconds per audio second: "
+                      "%.2f (MDX) + %.2f (RVC)" % (seconds_rvc, mdx_cost, rvc_cost)}
 
 
 def pmc_traffic_per_launch():
-    """HBM bytes per conv launch from the committed rocprofv3 PMC passes of this same command (profiles/r01_summary.json:
-    FETCH_SIZE + WRITE_SIZE, KiB units, summed over the conv kernels, uncorrected -- see DESIGN.md section 5); None when the
-    summary is absent.  The counters cannot be collected inside the timed run."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_summary.json")
-    try:
-        s = json.load(open(path))
-        f, w = s["FETCH_SIZE"], s["WRITE_SIZE"]
-        return (f["conv_kernels_sum"] / f["conv_kernels_calls"] + w["conv_kernels_sum"] / w["conv_kernels_calls"]) * 1024.0
-    except Exception:
-        return None
+    """HBM bytes per conv launch from the committed rocprofv3 PMC passes of this same command (profiles/r02_summary.json, falling
+    back to r01): FETCH_SIZE (x 2: the gfx950 under-report for wide reads, MI355X_MICROARCH.md) + WRITE_SIZE, KiB units, summed
+    over the conv kernels; None when no summary is committed.  The counters cannot be collected inside the timed run."""
+    for tag in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", "%s_summary.json" % tag)
+        try:
+            s = json.load(open(path))
+            f, w = s["FETCH_SIZE"], s["WRITE_SIZE"]
+            raw = (f["conv_kernels_sum"] / f["conv_kernels_calls"] + w["conv_kernels_sum"] / w["conv_kernels_calls"]) * 1024.0
+            cor = (2.0 * f["conv_kernels_sum"] / f["conv_kernels_calls"] + w["conv_kernels_sum"] / w["conv_kernels_calls"]) * 1024.0
+            return {"raw": raw, "fetch_x2": cor, "source": "profiles/%s_summary.json" % tag}
+        except Exception:
+            continue
+    return None
+
+
+def stage_table(conv, stages, steps):
+    """Per-stage roofline fractions (report per stage; STFT / iSTFT stand-alone)."""
+    rows = [{"stage": "conv family (implicit GEMM)", "bound": "mfma", "ms_per_step": conv["ms"] / steps,
+             "achieved": conv["tflops"], "unit": "TFLOP/s", "frac": conv["tflops"] / PEAK_F32_MFMA}]
+    for name, r in sorted(stages.items(), key=lambda kv: -kv[1]["ms"]):
+        if r["ms"] <= 0:
+            continue
+        if r["flops"] > 0:
+            a = r["flops"] / (r["ms"] * 1e-3) / 1e12
+            rows.append({"stage": name, "bound": "mfma", "ms_per_step": r["ms"] / steps, "achieved": a, "unit": "TFLOP/s",
+                         "frac": a / PEAK_F32_MFMA})
+        else:
+            a = r["bytes"] / (r["ms"] * 1e-3) / 1e9
+            rows.append({"stage": name, "bound": "hbm", "ms_per_step": r["ms"] / steps, "achieved": a, "unit": "GB/s",
+                         "frac": a / PEAK_HBM})
+    return rows
 
 
 def main():
@@ -114,8 +163,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", choices=["C2", "C3", "C4", "C5"], default="C3")
+    ap.add_argument("--mdx-models", type=int, default=1, choices=[1, 3])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--track-seconds", type=float, default=TRACK_S)
+    ap.add_argument("--track-seconds", type=float, default=None)
     ap.add_argument("--dump", type=str, default=None, help="write the last step's outputs (npz) for cross-checking runs")
     args = ap.parse_args()
 
@@ -138,37 +189,42 @@ def main():
             td.init_process_group(backend=backend, rank=rank, world_size=world)
 
     from aicovergen_amd import ops
-    from synthetic.inputs import song_like, vocal_like
-    seconds = args.track_seconds * world
-    mdx, vc, hub, net_g = build_models(device)
+    from synthetic.inputs import song_like
+    strong = args.config == "C5"
+    if strong:
+        seconds = args.track_seconds or 1800.0        # one track in total, sharded over the ranks
+    else:
+        seconds = (args.track_seconds or TRACK_S) * world   # weak scaling: 240 s per GPU
+    with contextlib.redirect_stdout(sys.stderr):      # the synthesizer constructors print like the reference's do
+        mdxs, vc, hub, net_g = build_models(device, args.config, args.mdx_models)
     wave44 = song_like(seconds, 44100, 1234)
     wave44 = wave44 / max(np.max(wave44), abs(np.min(wave44)))
     wave44_dev = torch.from_numpy(wave44).to(device)     # inputs resident in HBM before the timed region
-    wave16 = vocal_like(seconds, 16000, 1234)             # the RVC stage's own input format: host float32 @16 kHz
 
     def barrier():
         if world > 1:
             td.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_step(mdx, vc, hub, net_g, wave44_dev, wave16, group)
-    prof = None
-    if rank == 0:
-        prof = ops.ConvProfile()
-        ops.conv_profile = prof
-    barrier()
-    t0 = time.perf_counter()
-    stage = [0.0, 0.0, 0.0]
-    split = {}
-    for _ in range(args.steps):
-        sep, out, times, prof_s = one_step(mdx, vc, hub, net_g, wave44_dev, wave16, group)
-        stage = [a + b for a, b in zip(stage, times)]
-        for k, v in prof_s.items():
-            split[k] = split.get(k, 0.0) + v / args.steps
-    barrier()
-    dt = time.perf_counter() - t0
-    ops.conv_profile = None
+    with contextlib.redirect_stdout(sys.stderr):
+        for _ in range(args.warmup):
+            one_step(args.config, mdxs, vc, hub, net_g, wave44_dev, group)
+        prof = sprof = None
+        if rank == 0:
+            prof, sprof = ops.ConvProfile(), ops.StageProfile()
+            ops.conv_profile, ops.stage_profile = prof, sprof
+        barrier()
+        t0 = time.perf_counter()
+        stage = [0.0, 0.0, 0.0]
+        split = {}
+        for _ in range(args.steps):
+            sep, out, times, prof_s = one_step(args.config, mdxs, vc, hub, net_g, wave44_dev, group)
+            stage = [a + b for a, b in zip(stage, times)]
+            for k, v in prof_s.items():
+                split[k] = split.get(k, 0.0) + v / args.steps
+        barrier()
+        dt = time.perf_counter() - t0
+    ops.conv_profile = ops.stage_profile = None
     tmax = torch.tensor([dt], device=device, dtype=torch.float64)
     if world > 1:
         td.all_reduce(tmax, op=td.ReduceOp.MAX)
@@ -176,31 +232,45 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         conv = prof.summary()
+        workload = {
+            "C2": "C2: %d s 44.1 kHz stereo -> MDX-Net (%d model(s), Voc_FT-class 3072/256/7680, denoise) only",
+            "C3": "C3: %d s 44.1 kHz stereo -> MDX-Net (%d model(s), Voc_FT-class 3072/256/7680, denoise) -> vocals resampled on the "
+                  "device to 16 kHz mono -> RVC (HuBERT-base, RMVPE, SynthesizerTrnMs768NSFsid 40k)",
+            "C4": "C4: %d s 44.1 kHz stereo -> MDX-Net (%d model(s)) -> device resample -> RVC with mangio-crepe f0 (CREPE-full, hop 128)",
+            "C5": "C5: one %d s 44.1 kHz stereo track -> MDX-Net (%d model(s)) -> device resample -> RVC (rmvpe), sharded over the ranks",
+        }[args.config] % (int(seconds), args.mdx_models) + ", seeded random weights"
+        traffic = pmc_traffic_per_launch()
         res = {
             "metric": "real-time factor (audio-sec/wall-sec) for MDX+RVC on 4-min 44.1 kHz track",
             "value": seconds * args.steps / dt, "unit": "x real-time", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C3: %d s 44.1 kHz stereo -> MDX-Net (Voc_FT-class 3072/256/7680, denoise) + RVC (HuBERT-base, "
-                                   "RMVPE, SynthesizerTrnMs768NSFsid 40k), seeded random weights" % int(seconds),
-                       "audio_seconds_per_gpu": args.track_seconds, "rvc_preset": "x_pad,x_query,x_center,x_max=3,10,60,65",
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "config_id": args.config, "mdx_models": args.mdx_models,
+                       "audio_seconds_total": seconds, "rvc_preset": "x_pad,x_query,x_center,x_max=3,10,60,65",
+                       "stage_handover": "device (aicg_resample_poly); excluded like in the reference's metric: model load, WAV "
+                                         "read/write, main.py mixing",
                        "sharding": "mdx windows + rvc chunks over %d rank(s), all-gather join" % world,
                        "stage_seconds_per_step": {"hubert": stage[0] / args.steps, "f0": stage[1] / args.steps,
                                                   "synth": stage[2] / args.steps},
                        "wall_split_seconds_per_step": split},
-            "roofline": {"bound": "mfma", "achieved": conv["tflops"], "peak": 157.3, "unit": "TFLOP/s",
-                         "frac": conv["tflops"] / 157.3, "traffic": pmc_traffic_per_launch(),
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE + WRITE_SIZE, profiles/r01_summary.json)",
-                         "kernel": "conv_ws_kernel family (fp32 MFMA implicit GEMM: conv_ws / conv_ws16 / conv_mfma / conv_mfma16)",
+            "roofline": {"bound": "mfma", "achieved": conv["tflops"], "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
+                         "frac": conv["tflops"] / PEAK_F32_MFMA,
+                         "traffic": None if traffic is None else traffic["fetch_x2"],
+                         "traffic_unit": None if traffic is None else
+                         "HBM bytes per launch: rocprofv3 2 x FETCH_SIZE + WRITE_SIZE (%s); uncorrected %.4g" % (traffic["source"],
+                                                                                                                traffic["raw"]),
+                         "kernel": "conv family (fp32 MFMA implicit GEMM: conv_ws3 / conv_ws / conv_ws16 / conv_mfma)",
                          "launches_per_step": conv["launches"] / args.steps,
                          "algorithmic_tflop_per_step": conv["flops"] / args.steps / 1e12,
                          "algorithmic_bytes_per_launch": conv["bytes"] / max(1, conv["launches"]),
                          "kernel_ms_per_step": conv["ms"] / args.steps},
+            "stages": stage_table(conv, sprof.summary(), args.steps),
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline()
+            with contextlib.redirect_stdout(sys.stderr):
+                res["cpu_baseline"] = cpu_baseline()
         if args.dump:
-            np.savez_compressed(args.dump, sep=sep.cpu().numpy()[:, ::7], out=out)
+            np.savez_compressed(args.dump, sep=sep.cpu().numpy()[:, ::7], out=out if out is not None else np.zeros(1))
         print(json.dumps(res))
     if world > 1:
         td.destroy_process_group()

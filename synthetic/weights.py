@@ -236,6 +236,11 @@ def rmvpe_state_dict(cfg=RMVPE_FULL, seed=1234):
 # ---------------------------------------------------------------------------------------------------
 MDX_VOC_FT = dict(dim_c=4, g=48, n=5, l=3, k=3, bn=8, dim_f=3072, dim_t=256, n_fft=7680)   # model_data.json Voc_FT class
 MDX_TINY = dict(dim_c=4, g=8, n=2, l=2, k=3, bn=4, dim_f=64, dim_t=16, n_fft=160)
+# The other two separations of main.py's chain (src/main.py:185,188: UVR_MDXNET_KARA_2, Reverb_HQ_By_FoxJoy).  Which hash of
+# model_data.json belongs to which file cannot be derived offline; these are two of the (dim_f, dim_t, n_fft) classes that json
+# lists -- (2048, 2^8, 5120) and (3072, 2^9, 6144) -- with the Voc_FT-class channel plan [MEM-EST].
+MDX_KARA2 = dict(dim_c=4, g=48, n=5, l=3, k=3, bn=8, dim_f=2048, dim_t=256, n_fft=5120)
+MDX_REVERB_HQ = dict(dim_c=4, g=48, n=5, l=3, k=3, bn=8, dim_f=3072, dim_t=512, n_fft=6144)
 
 
 def _bn2(sd, g, name, c):
