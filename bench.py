@@ -73,7 +73,9 @@ def one_step(config, mdxs, vc, hub, net_g, wave44_dev, group):
     from aicovergen_amd import ops
     t0 = time.perf_counter()
     sep = wave44_dev
-    for m in mdxs:   # main.py feeds each separation the previous one's stem
+    for i, m in enumerate(mdxs):   # main.py feeds each separation the previous one's stem; run_mdx peak-normalises its input
+        if i > 0:
+            sep = sep / ops.absmax(sep.reshape(-1)).clamp_min(1e-12)   # (mdx.py:258-259)
         sep = adist.mdx_separate(m, sep, True, 2, group)
     torch.cuda.synchronize()  # stage boundary (the reference writes the stems to disk here)
     mdx_s = time.perf_counter() - t0
