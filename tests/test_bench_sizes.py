@@ -182,3 +182,22 @@ def test_mdx_16_window_batch_vs_oracle_and_window_counts():
             e = rel_rms(got[w:w + 1], ref)
             print("MDX window %d of the 16-image batch: rel rms %.3e" % (w, e))
             assert e < 1e-4
+
+
+@pytest.mark.parametrize("name", ["MDX_KARA2", "MDX_REVERB_HQ"])
+def test_other_mdx_geometries_vs_oracle(name):
+    """The (dim_f, dim_t, n_fft) classes of the other two separations in main.py's chain (src/main.py:185,188): (2048, 256, 5120)
+    -- a radix-5 FFT length -- and (3072, 512, 6144); one window through stft -> U-Net -> istft vs the oracle."""
+    from aicovergen_amd.mdx import MDX, MDXModel
+    cfg = getattr(weights, name)
+    sd = weights.mdx_state_dict(cfg, 4321)
+    model = MDXModel("cuda:0", cfg["dim_f"], cfg["dim_t"], cfg["n_fft"])
+    sess = MDX(None, model, state_dict=sd)
+    assert model.chunk_size == 1024 * (cfg["dim_t"] - 1)
+    x = torch.from_numpy(song_like(model.chunk_size / 44100.0 + 0.01, 44100, seed=8)[:, :model.chunk_size]).unsqueeze(0)
+    with torch.no_grad():
+        ref = mdxnet.istft(mdxnet.unet(sd, cfg, mdxnet.stft(x, cfg["n_fft"], 1024, cfg["dim_f"])), cfg["n_fft"], 1024)
+        got = model.istft_tf(sess.net.forward_tf(model.stft_tf(x.cuda())))
+    e = rel_rms(got, ref)
+    print("%s window: rel rms %.3e" % (name, e))
+    assert e < 1e-4
