@@ -123,6 +123,7 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
     Ho = d->Ho; Wo = d->Wo;
     if (d->N == 0 || Ho <= 0 || Wo <= 0) return AICG_OK;
     ConvArgs p;
+    p.stagger = p.stagger_first = p.wide_ok = 0;
     p.x = x; p.w = w_packed; p.bias = bias; p.res = res; p.y = y;
     p.N = d->N; p.Cin_g = d->Cin / d->groups; p.H = d->H; p.W = d->W; p.Cout_g = d->Cout / d->groups;
     p.Ho = Ho; p.Wo = Wo; p.KH = d->KH; p.KW = d->KW; p.sh = d->stride_h; p.sw = d->stride_w;

@@ -1003,6 +1003,68 @@ __device__ __forceinline__ void ws_epilogue16(const ConvArgs& p, f32x4 (&acc)[TM
     dispatch_epilogue(p.act, interior, epilogue);
 }
 
+// float4 epilogue of the 16x16x4 kernels (interior tiles, plain addressing, aligned rows): per 16-row block a wave's 16 x 64 outputs
+// take the detour through a per-wave LDS scratch (16 ds_write_b32 + 4 ds_read_b128) and leave as 4 global_store_dwordx4 covering
+// 4 rows x 256 B each, instead of 16 dword stores per lane (see ws_epilogue32_wide).
+static constexpr int kEpi16Row = 68;                  // 64 positions + 4
+static constexpr int kEpi16Scratch = 16 * kEpi16Row;  // floats per consumer wave
+template <int TM, int TN>
+__device__ __forceinline__ void ws_epilogue16_wide(const ConvArgs& p, f32x4 (&acc)[TM][TN], int n, int g, int m_base, int nl0, int h0, int w0,
+                                                   int lane, float* scratch) {
+    static_assert(TN == 4, "a consumer wave covers 64 positions");
+    const int r16 = lane & 15, q = lane >> 4;
+    const int rrow = lane >> 4, rcol = (lane & 15) * 4;   // after the detour: rows rrow + 4 pass, positions rcol .. rcol + 3
+    float* wr = scratch + (4 * q) * kEpi16Row + r16;
+    const float4* rd = reinterpret_cast<const float4*>(scratch + rrow * kEpi16Row + rcol);
+    const int nl = nl0 + rcol;
+    const int ho = h0 + (nl >> p.TWlog2), wo = w0 + (nl & (p.TW - 1));
+    const long y_col = (long)n * p.y_sn + (long)ho * p.y_sh + wo, r_col = (long)n * p.r_sn + (long)ho * p.r_sh + wo;
+    auto body = [&](auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) wr[r * kEpi16Row + j * 16] = acc[i][j][r];
+            __builtin_amdgcn_wave_barrier();
+            const long co0 = (long)g * p.Cout_g + m_base + i * 16 + rrow;
+            float4 rv[4], yv[4], v[4];
+            if (p.res) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) rv[t] = *reinterpret_cast<const float4*>(p.res + r_col + (co0 + 4 * t) * p.r_sc);
+            }
+            if (p.accumulate) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) yv[t] = *reinterpret_cast<const float4*>(p.y + y_col + (co0 + 4 * t) * p.y_sc);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = rd[t * 4 * (kEpi16Row / 4)];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float e[4] = {v[t].x, v[t].y, v[t].z, v[t].w};
+                const float rr[4] = {p.res ? rv[t].x : 0.f, p.res ? rv[t].y : 0.f, p.res ? rv[t].z : 0.f, p.res ? rv[t].w : 0.f};
+                const float yy[4] = {p.accumulate ? yv[t].x : 0.f, p.accumulate ? yv[t].y : 0.f, p.accumulate ? yv[t].z : 0.f,
+                                     p.accumulate ? yv[t].w : 0.f};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float x = e[u];
+                    if (p.res_first) x += rr[u];
+                    x = act_static<ACT>(x, p.act, p.act_slope);
+                    if (!p.res_first) x += rr[u];
+                    e[u] = x * p.out_scale + yy[u];
+                }
+                *reinterpret_cast<float4*>(p.y + y_col + (co0 + 4 * t) * p.y_sc) = make_float4(e[0], e[1], e[2], e[3]);
+            }
+        }
+    };
+    if (p.act == AICG_ACT_NONE) body(std::integral_constant<int, 0>{});
+    else if (p.act == AICG_ACT_RELU) body(std::integral_constant<int, 1>{});
+    else if (p.act == AICG_ACT_LRELU) body(std::integral_constant<int, 2>{});
+    else body(std::integral_constant<int, 3>{});
+}
+
 // Wave-specialised narrow-M kernel: the consumers of conv_mfma16_kernel (16x16x4 MFMA, every wave covers all BM rows x 64
 // positions of a 256-position tile) fed by ws_produce.  WsGeom pads the weight stage with 4 slack rows (one 16x16x4 k-step).
 template <int BM, int XR, int KS, bool GEN>
@@ -1083,7 +1145,12 @@ __global__ void __launch_bounds__(512, 4) conv_ws16_kernel(ConvArgs p) {
         }
     }
     const bool interior = m_base + BM <= p.Cout_g && h0 + p.TH <= p.Ho && w0 + p.TW <= p.Wo;
-    ws_epilogue16<TM, TN, GEN>(p, acc, n, g, m_base, wn * 64, h0, w0, r16, q, interior);
+    if (!GEN && interior && p.wide_ok) {
+        lds_barrier();   // consumers only: every wave is done with the last stage, LDS is free
+        ws_epilogue16_wide<TM, TN>(p, acc, n, g, m_base, wn * 64, h0, w0, lane, smem + wn * kEpi16Scratch);
+    } else {
+        ws_epilogue16<TM, TN, GEN>(p, acc, n, g, m_base, wn * 64, h0, w0, r16, q, interior);
+    }
 }
 
 inline int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
@@ -1258,6 +1325,10 @@ static int launch_conv16(ConvArgs& p, hipStream_t stream) {
         const int xrw = xr <= 8 ? 8 : 12;
         const size_t ldsw = (size_t)(2 * xrw * 256 + 2 * WsGeom<BM, KSTAGE>::WS_ELEMS) * sizeof(float);
         const bool gen = p.shuffle || p.res_mul;
+        {
+            static const int wide = getenv("AICG_CONV_WIDE") ? atoi(getenv("AICG_CONV_WIDE")) : 1;
+            p.wide_ok = wide ? conv_wide_ok(p) : 0;
+        }
         auto kern = gen ? (xrw == 8 ? conv_ws16_kernel<BM, 8, KSTAGE, true> : conv_ws16_kernel<BM, 12, KSTAGE, true>)
                         : (xrw == 8 ? conv_ws16_kernel<BM, 8, KSTAGE, false> : conv_ws16_kernel<BM, 12, KSTAGE, false>);
         allow_dynamic_lds((const void*)kern, ldsw);
