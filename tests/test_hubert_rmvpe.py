@@ -1,6 +1,8 @@
 """HuBERT feature extractor and RMVPE f0 estimator on the HIP kernels vs the oracle restatements
 (oracle/hubert.py pinned against transformers.HubertModel, oracle/rmvpe.py pinned against the reference's own
 src/rmvpe.py -- see tests/test_oracle_golden.py)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -154,3 +156,22 @@ def test_gru_kernels_match_torch(dev, hidden, T):
         got = ops.gru_bidir(dev.t(gi), dev.t(whh_t.contiguous()), dev.t(bhh), hidden, two_workgroups=two)
         ops.gru_check_pending()
         assert rel_rms(got, ref) < 1e-5, "two_workgroups=%s" % two
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.environ.get("AICG_REAL_HUBERT"), reason="set AICG_REAL_HUBERT=<hubert_base.pt> (and install fairseq) to pin HuBERT")
+def test_real_hubert_checkpoint_matches_fairseq():
+    """The one-command pin of row a6: fairseq's own HubertModel.extract_features (what the reference calls,
+    src/vc_infer_pipeline.py:398-406) against this implementation loaded from the same checkpoint."""
+    import conftest
+    fairseq = pytest.importorskip("fairseq")
+    conftest._bind("hip")
+    from aicovergen_amd.rvc import load_hubert
+    path = os.environ["AICG_REAL_HUBERT"]
+    models, _, _ = fairseq.checkpoint_utils.load_model_ensemble_and_task([path], suffix="")
+    ref_model = models[0].float().eval()
+    wav = torch.from_numpy(vocal_like(4.0, 16000, seed=3)).unsqueeze(0)
+    with torch.no_grad():
+        ref = ref_model.extract_features(source=wav, padding_mask=torch.zeros_like(wav, dtype=torch.bool), output_layer=12)[0]
+    got = load_hubert("cuda:0", False, path).extract_features(source=wav, padding_mask=None, output_layer=12)[0]
+    assert rel_rms(got, ref) < 1e-4

@@ -110,3 +110,26 @@ def test_run_mdx_end_to_end_from_onnx_and_wav_files(tmp_path):
     tol = 2 * lsb + 1e-4 * max(1.0, float(np.abs(ref_main).max()), float(np.abs(ref_inv).max()))
     assert np.abs(got_main - np.clip(ref_main, -1, 1)).max() < tol
     assert np.abs(got_inv - np.clip(ref_inv, -1, 1)).max() < tol
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.environ.get("AICG_REAL_ONNX"), reason="set AICG_REAL_ONNX=<UVR .onnx> (and install onnxruntime) to pin the U-Net")
+def test_real_uvr_onnx_matches_onnxruntime():
+    """The one-command pin of row a2: a published UVR-MDX-NET .onnx run by onnxruntime (what the reference does, src/mdx.py:74-77,193)
+    against the U-Net rebuilt from the same file's initializers on the HIP kernels, on one window."""
+    import json
+    import conftest
+    ort = pytest.importorskip("onnxruntime")
+    conftest._bind("hip")
+    from aicovergen_amd.mdx import MDX, MDXModel
+    path = os.environ["AICG_REAL_ONNX"]
+    data = json.load(open(os.environ.get("AICG_MODEL_DATA", os.path.join(os.path.dirname(path), "model_data.json"))))
+    mp = data[MDX.get_hash(path)]
+    model = MDXModel("cuda:0", dim_f=mp["mdx_dim_f_set"], dim_t=2 ** mp["mdx_dim_t_set"], n_fft=mp["mdx_n_fft_scale_set"],
+                     stem_name=mp["primary_stem"], compensation=mp["compensate"])
+    sess = MDX(path, model)
+    x = torch.randn(1, 2, model.chunk_size) * 0.1
+    spec = model.stft(x.cuda())
+    ref = ort.InferenceSession(path, providers=["CPUExecutionProvider"]).run(None, {"input": spec.cpu().numpy()})[0]
+    got = sess.process(spec).cpu().numpy()
+    assert np.abs(got - ref).max() < 1e-3 * np.abs(ref).max()
