@@ -10,6 +10,9 @@
 
 #include "common.h"
 
+#include <cstdint>
+#include <cstdlib>
+
 namespace aicg {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -26,6 +29,8 @@ struct GemmArgs {
     int K, O;
     long lda, ldw, ldc, ldr;
     int rows_per_ch, n_ch, act;
+    int order;
+    int wide;   // c, res (and bias) are 16-byte aligned with row strides that are multiples of 4: interior tiles may use float4
 };
 
 static constexpr int GK = 32;        // K per stage
@@ -33,13 +38,25 @@ static constexpr int GLD = GK + 1;   // LDS row stride
 
 // 128 x 128 tile, 4 waves as 2 x 2, each wave 64 x 64 (2 x 2 MFMA tiles)
 __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmArgs p) {
-    __shared__ float As[128 * GLD + 4];
-    __shared__ float Ws[128 * GLD + 4];
+    __shared__ __attribute__((aligned(16))) float As[128 * GLD + 4];
+    __shared__ __attribute__((aligned(16))) float Ws[128 * GLD + 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int wm = wave >> 1, wn = wave & 1;
-    const long r0 = (long)blockIdx.x * 128;
-    const int o0 = blockIdx.y * 128;
+    // tile order (order == 1): column tiles fastest inside groups of 8 consecutive ids, groups dealt to the XCDs -- the workgroups
+    // that share a row tile of A run back to back behind one L2 instead of re-streaming A once per column tile
+    long r0;
+    int o0;
+    if (p.order == 0) {
+        r0 = (long)blockIdx.x * 128;
+        o0 = blockIdx.y * 128;
+    } else {
+        const unsigned nx = gridDim.x, ny = gridDim.y;
+        const unsigned flat = blockIdx.y * nx + blockIdx.x;
+        const unsigned tile = xcd_remap(flat, nx * ny);
+        r0 = (long)(tile / ny) * 128;
+        o0 = (int)(tile % ny) * 128;
+    }
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -146,6 +163,64 @@ __global__ void __launch_bounds__(256) gemm_nt_kernel(GemmArgs p) {
             }
         }
     };
+    // Interior tiles with 16-byte-aligned rows: float4 epilogue.  A lane owns one column o and 16 rows per 32 x 32 tile -- 16 dword
+    // stores (+ 16 residual loads) per tile, and the tail of a tile is bound by the NUMBER of memory instructions (the f/8 -> f
+    // expansion has only 12 K stages per tile against 64 + 64 of them).  Each tile takes a detour through a per-wave LDS scratch
+    // that turns the layout into 4 consecutive columns per lane: 4 float4 stores (8 rows x 128 B each) and 4 float4 residual loads.
+    const bool wide = p.wide && r0 + 128 <= p.R && o0 + 128 <= p.O && ch_per_tile == (p.row_scale != nullptr);
+    if (wide) {
+        constexpr int SR = 36;
+        __syncthreads();   // every wave is done reading the last K stage: As / Ws are free
+        float* scratch = (wave < 2 ? As : Ws) + (wave & 1) * (32 * SR);   // 2 x 1152 floats per stage buffer (4228 each)
+        float* wr = scratch + (4 * half) * SR + l31;
+        const int rrow = lane >> 3, rcol = (lane & 7) * 4;
+        const float4* rd = reinterpret_cast<const float4*>(scratch + rrow * SR + rcol);
+        auto wide_body = [&](auto act_tag) {
+            constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int o = o0 + wn * 64 + j * 32 + rcol;
+                float4 bo = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.bias) bo = *reinterpret_cast<const float4*>(p.bias + o);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const long rt = r0 + wm * 64 + i * 32;
+                    float sc = 1.f, sh = 0.f;
+                    if (p.row_scale) {
+                        const int ch = (int)((rt / p.rows_per_ch) % p.n_ch);
+                        sc = p.row_scale[ch]; sh = p.row_shift[ch];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int rg = 0; rg < 16; ++rg) wr[((rg & 3) + 8 * (rg >> 2)) * SR] = acc[i][j][rg];
+                    __builtin_amdgcn_wave_barrier();
+                    float4 rv[4], v[4];
+                    if (p.res) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) rv[q] = *reinterpret_cast<const float4*>(p.res + (rt + rrow + 8 * q) * p.ldr + o);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = rd[q * 8 * (SR / 4)];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float e[4] = {v[q].x + bo.x, v[q].y + bo.y, v[q].z + bo.z, v[q].w + bo.w};
+                        const float rr[4] = {p.res ? rv[q].x : 0.f, p.res ? rv[q].y : 0.f, p.res ? rv[q].z : 0.f, p.res ? rv[q].w : 0.f};
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            float x = e[t] * sc + sh;
+                            x = ACT == 0 ? x : ACT == 1 ? (x > 0.f ? x : 0.f) : apply_act(x, p.act, 0.f);
+                            e[t] = x + rr[t];
+                        }
+                        *reinterpret_cast<float4*>(p.c + (rt + rrow + 8 * q) * p.ldc + o) = make_float4(e[0], e[1], e[2], e[3]);
+                    }
+                }
+            }
+        };
+        if (p.act == AICG_ACT_NONE) wide_body(std::integral_constant<int, 0>{});
+        else if (p.act == AICG_ACT_RELU) wide_body(std::integral_constant<int, 1>{});
+        else wide_body(std::integral_constant<int, 2>{});
+        return;
+    }
     if (p.act == AICG_ACT_NONE) epilogue(std::integral_constant<int, 0>{});
     else if (p.act == AICG_ACT_RELU) epilogue(std::integral_constant<int, 1>{});
     else epilogue(std::integral_constant<int, 2>{});
@@ -166,7 +241,12 @@ extern "C" int aicg_gemm_nt(const float* a, const float* w, const float* bias, c
         return fail(AICG_E_SHAPE, "aicg_gemm_nt: K, lda and ldw must be multiples of 4 (float4 loads)");
     if (R == 0) return AICG_OK;
     GemmArgs p{a, w, bias, row_scale, row_shift, res, c, (long)R, K, O, (long)lda, (long)ldw, (long)ldc, (long)ldr,
-               rows_per_ch, n_ch, act};
+               rows_per_ch, n_ch, act, 0, 0};
+    static const int order = getenv("AICG_GEMM_ORDER") ? atoi(getenv("AICG_GEMM_ORDER")) : 1;
+    static const int wide = getenv("AICG_GEMM_WIDE") ? atoi(getenv("AICG_GEMM_WIDE")) : 1;
+    p.order = order;
+    auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    p.wide = wide && al(c) && (ldc & 3) == 0 && (!res || (al(res) && (ldr & 3) == 0)) && (!bias || al(bias)) && (O & 3) == 0;
     dim3 grid((unsigned)ldiv_up(R, 128), (unsigned)idiv_up(O, 128));
     hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("gemm_nt_kernel");
