@@ -87,8 +87,7 @@ __global__ void __launch_bounds__(64) iir_blocks_kernel(const double* __restrict
     const double x0 = at(0);
 #pragma unroll
     for (int q = 0; q < IIR_MAX; ++q) z[q] = (js == 0 && q < f.order) ? f.zi[q] * x0 : 0.0;
-    for (long j = js; j < j1; ++j) {
-        const double xv = at(j);
+    auto step = [&](long j, double xv) {
         const double y = z[0] + f.b[0] * xv;
         // coefficients beyond the filter order are zero, so the states beyond it stay zero
 #pragma unroll
@@ -98,7 +97,18 @@ __global__ void __launch_bounds__(64) iir_blocks_kernel(const double* __restrict
             const long o = j - out_off;
             if (reverse) out[out_len - 1 - o] = y; else out[o] = y;
         }
+    };
+    // the recurrence is a dependent chain, the loads are not: 8 samples are fetched ahead of the 8 steps that consume them
+    // (one load per step left every step waiting a full memory round trip: 3.2 ms per pass on a 4-minute track)
+    long j = js;
+    for (; j + 8 <= j1; j += 8) {
+        double xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xv[u] = at(j + u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) step(j + u, xv[u]);
     }
+    for (; j < j1; ++j) step(j, at(j));
 }
 
 // ---- polyphase resampling -------------------------------------------------------------------------------------------------------------

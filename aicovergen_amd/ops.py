@@ -733,7 +733,7 @@ def _filtfilt_plan(b, a):
     return _filtfilt_plans[key]
 
 
-def filtfilt_f64(x, b, a, block=8192):
+def filtfilt_f64(x, b, a, block=1024):
     """scipy.signal.filtfilt(b, a, x) (default odd padding / lfilter_zi) of a float64 device signal, block-parallel."""
     x = x.contiguous().double()
     bb, aa, zi, order, padlen, warm = _filtfilt_plan(b, a)
