@@ -213,6 +213,9 @@ def _collect_layers(nodes, inits):
                 other = [i for i in add["input"] if i != out]
                 if other and other[0] in inits and inits[other[0]].ndim == 1:
                     b, out = inits[other[0]], add["output"][0]
+        elif op in ("Gemm", "Einsum", "ConvInteger", "MatMulInteger", "QLinearConv", "QLinearMatMul"):
+            raise ValueError("onnx: parameterised node %r (%s) is not part of the TFC-TDF U-Net this reader maps "
+                             "(Conv / ConvTranspose / MatMul [+ Add] [+ BatchNormalization])" % (nd["name"], op))
         else:
             continue
         bn = None
@@ -220,6 +223,26 @@ def _collect_layers(nodes, inits):
         if bnode is not None:
             g, be, mu, var = (inits[i] for i in bnode["input"][1:5])
             bn = (g, be, mu, var, float(bnode["attr"].get("epsilon", 1e-5)))
+        else:
+            # graph optimisers rewrite an eval-mode BatchNormalization as Mul(per-channel scale) [-> Add(per-channel shift)] with
+            # (1, C, 1, 1) constants; taken as gamma = scale, beta = shift over unit statistics.  Anything else that is not a
+            # plain activation between two parameterised layers is refused below rather than skipped.
+            def chan_const(node):
+                other = [i for i in node["input"] if i != cur]
+                c = inits.get(other[0]) if other else None
+                if c is None:
+                    return None
+                c = np.asarray(c)
+                return c.reshape(-1) if c.ndim in (3, 4) and c.size == c.shape[-3] else None
+            cur = out
+            mul = follow(cur, "Mul")
+            scale = chan_const(mul) if mul is not None else None
+            if scale is not None:
+                cur = mul["output"][0]
+                add = follow(cur, "Add")
+                shift = chan_const(add) if add is not None else None
+                bn = (scale, shift if shift is not None else np.zeros_like(scale), np.zeros_like(scale),
+                      np.full_like(scale, 1.0 - _BN_EPS), _BN_EPS)
         kind = {"Conv": "conv", "ConvTranspose": "convT", "MatMul": "linear"}[op]
         layers.append({"kind": kind, "w": w, "b": b, "bn": bn, "attr": nd["attr"]})
     return layers

@@ -2,6 +2,7 @@
 onto kuielab ConvTDFNet parameter names, and the separator running from an `.onnx` path like the reference's
 `MDX(model_path, ...)` does (src/mdx.py:74-77)."""
 import os
+import struct
 import warnings
 
 import numpy as np
@@ -133,3 +134,162 @@ def test_real_uvr_onnx_matches_onnxruntime():
     ref = ort.InferenceSession(path, providers=["CPUExecutionProvider"]).run(None, {"input": spec.cpu().numpy()})[0]
     got = sess.process(spec).cpu().numpy()
     assert np.abs(got - ref).max() < 1e-3 * np.abs(ref).max()
+
+
+# ---- graphs that do NOT come from this repository's own torch.onnx.export -------------------------------------------------------
+# A minimal ONNX writer (protobuf wire format by hand) builds TFC-TDF U-Nets the way other exporters / graph optimisers lay them
+# out; the reader must either map them to the same parameters or refuse them.
+def _vi(v):
+    out = bytearray()
+    v &= (1 << 64) - 1
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        out.append(b | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def _ld(fno, payload):
+    return _vi((fno << 3) | 2) + _vi(len(payload)) + payload
+
+
+def _tensor_proto(name, arr):
+    arr = np.ascontiguousarray(arr, dtype=np.float32)
+    return b"".join(_vi((1 << 3) | 0) + _vi(d) for d in arr.shape) + _vi((2 << 3) | 0) + _vi(1) + _ld(8, name.encode()) + _ld(9, arr.tobytes())
+
+
+def _node_proto(op, inputs, outputs, name, ints=None, floats=None):
+    body = b"".join(_ld(1, i.encode()) for i in inputs) + b"".join(_ld(2, o.encode()) for o in outputs)
+    body += _ld(3, name.encode()) + _ld(4, op.encode())
+    for k, v in (ints or {}).items():
+        vals = v if isinstance(v, (list, tuple)) else [v]
+        att = _ld(1, k.encode()) + (b"".join(_vi((8 << 3) | 0) + _vi(x) for x in vals) if isinstance(v, (list, tuple))
+                                    else _vi((3 << 3) | 0) + _vi(v))
+        body += _ld(5, att)
+    for k, v in (floats or {}).items():
+        body += _ld(5, _ld(1, k.encode()) + _vi((2 << 3) | 5) + struct.pack("<f", v))
+    return body
+
+
+class _GraphWriter:
+    def __init__(self):
+        self.nodes, self.inits, self.n = [], [], 0
+
+    def const(self, arr):
+        self.n += 1
+        name = "c%d" % self.n
+        self.inits.append(_tensor_proto(name, arr))
+        return name
+
+    def node(self, op, inputs, **kw):
+        self.n += 1
+        out = "t%d" % self.n
+        self.nodes.append(_node_proto(op, inputs, [out], "%s_%d" % (op, self.n), **kw))
+        return out
+
+    def save(self, path):
+        graph = b"".join(_ld(1, n) for n in self.nodes) + b"".join(_ld(5, t) for t in self.inits)
+        open(path, "wb").write(_vi((1 << 3) | 0) + _vi(7) + _ld(7, graph))
+
+
+def _write_variant(path, sd, cfg, fuse_conv_bn, tdf_affine, transposes, linear_op="MatMul"):
+    """ConvTDFNet.forward as an ONNX graph.  fuse_conv_bn: BatchNorm folded into the Conv weights (what torch's exporter does) or
+    kept as BatchNormalization nodes; tdf_affine: "bn" | "muladd" (eval BatchNorm rewritten as Mul + Add constants);
+    transposes: the (F, T) <-> (T, F) Transpose nodes of the published forward()."""
+    g = _GraphWriter()
+    eps = 1e-5
+
+    def bn_params(name):
+        return [sd[name + s].numpy() for s in (".weight", ".bias", ".running_mean", ".running_var")]
+
+    def conv(x, name, op="Conv", stride=1):
+        w, b = sd[name + ".0.weight"].numpy(), sd[name + ".0.bias"].numpy()
+        ga, be, mu, var = bn_params(name + ".1")
+        k = w.shape[-1]
+        ints = {"kernel_shape": [k, k], "strides": [stride, stride], "pads": [k // 2 if stride == 1 and k > 1 else 0] * 4}
+        if fuse_conv_bn and op == "Conv":
+            s = ga / np.sqrt(var + eps)
+            y = g.node(op, [x, g.const(w * s[:, None, None, None]), g.const((b - mu) * s + be)], ints=ints)
+        else:
+            y = g.node(op, [x, g.const(w), g.const(b)], ints=ints)
+            y = g.node("BatchNormalization", [y] + [g.const(v) for v in (ga, be, mu, var)], floats={"epsilon": eps})
+        return g.node("Relu", [y])
+
+    def tfc_tdf(x, name):
+        for j in range(cfg["l"]):
+            x = conv(x, "%s.tfc.H.%d" % (name, j))
+        y = x
+        for idx in (0, 3):
+            w, b = sd["%s.tdf.%d.weight" % (name, idx)].numpy(), sd["%s.tdf.%d.bias" % (name, idx)].numpy()
+            if linear_op == "Gemm":
+                y = g.node("Gemm", [y, g.const(w.T), g.const(b)])
+            else:
+                y = g.node("MatMul", [y, g.const(w.T)])
+                if np.any(b != 0):
+                    y = g.node("Add", [y, g.const(b)])
+            ga, be, mu, var = bn_params("%s.tdf.%d" % (name, idx + 1))
+            if tdf_affine == "bn":
+                y = g.node("BatchNormalization", [y] + [g.const(v) for v in (ga, be, mu, var)], floats={"epsilon": eps})
+            else:
+                s = ga / np.sqrt(var + eps)
+                y = g.node("Mul", [y, g.const(s.reshape(1, -1, 1, 1))])
+                y = g.node("Add", [y, g.const((be - mu * s).reshape(1, -1, 1, 1))])
+            y = g.node("Relu", [y])
+        return g.node("Add", [x, y])
+
+    x = conv("input", "first_conv")
+    if transposes:
+        x = g.node("Transpose", [x], ints={"perm": [0, 1, 3, 2]})
+    skips = []
+    for i in range(cfg["n"]):
+        x = tfc_tdf(x, "ds_dense.%d" % i)
+        skips.append(x)
+        x = conv(x, "ds.%d" % i, stride=2)
+    x = tfc_tdf(x, "mid_dense")
+    for i in range(cfg["n"]):
+        x = conv(x, "us.%d" % i, op="ConvTranspose", stride=2)
+        x = g.node("Mul", [x, skips[-i - 1]])
+        x = tfc_tdf(x, "us_dense.%d" % i)
+    if transposes:
+        x = g.node("Transpose", [x], ints={"perm": [0, 1, 3, 2]})
+    g.node("Conv", [x, g.const(sd["final_conv.0.weight"].numpy()), g.const(sd["final_conv.0.bias"].numpy())], ints={"kernel_shape": [1, 1]})
+    g.save(path)
+
+
+@pytest.mark.parametrize("fuse_conv_bn,tdf_affine,transposes,bias", [
+    (False, "bn", True, True),        # nothing folded, explicit Transpose nodes, tdf linears with bias
+    (True, "muladd", True, False),    # an optimiser's output: Conv+BN folded, tdf BatchNorm as Mul + Add constants, bias-less MatMul
+    (False, "muladd", False, True),
+])
+def test_foreign_graph_layouts_map_to_the_same_network(tmp_path, fuse_conv_bn, tdf_affine, transposes, bias):
+    cfg = dict(CFG, n=1, l=2)
+    sd0 = weights.mdx_state_dict(cfg, 21)
+    if not bias:
+        for k in list(sd0):
+            if ".tdf." in k and k.endswith((".0.bias", ".3.bias")):
+                sd0[k] = torch.zeros_like(sd0[k])
+    p = str(tmp_path / "foreign.onnx")
+    _write_variant(p, sd0, cfg, fuse_conv_bn, tdf_affine, transposes)
+    nodes, _ = onnx_weights.parse_model(p)
+    assert ("Transpose" in [n["op"] for n in nodes]) == transposes
+    sd1 = onnx_weights.load_onnx_state_dict(p)
+    spec = torch.randn(1, cfg["dim_c"], cfg["dim_f"], cfg["dim_t"])
+    with torch.no_grad():
+        assert rel_rms(mdxnet.unet(sd1, cfg, spec), mdxnet.unet(sd0, cfg, spec)) < 5e-6
+
+
+def test_foreign_graph_with_unmapped_parameter_nodes_is_refused(tmp_path):
+    cfg = dict(CFG, n=1, l=2)
+    p = str(tmp_path / "gemm.onnx")
+    _write_variant(p, weights.mdx_state_dict(cfg, 22), cfg, True, "bn", True, linear_op="Gemm")
+    with pytest.raises(ValueError, match="Gemm"):
+        onnx_weights.load_onnx_state_dict(p)
+    # a network with a different block structure (one tfc conv removed from the middle) is refused by the sequence check
+    g = _GraphWriter()
+    x = g.node("Conv", ["input", g.const(np.zeros((8, 4, 1, 1))), g.const(np.zeros(8))], ints={"kernel_shape": [1, 1]})
+    x = g.node("MatMul", [x, g.const(np.zeros((64, 16)))])
+    g.node("Conv", [x, g.const(np.zeros((4, 8, 1, 1))), g.const(np.zeros(4))], ints={"kernel_shape": [1, 1]})
+    g.save(str(tmp_path / "odd.onnx"))
+    with pytest.raises(ValueError, match="not a TFC-TDF U-Net|does not match"):
+        onnx_weights.load_onnx_state_dict(str(tmp_path / "odd.onnx"))
