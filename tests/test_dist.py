@@ -108,7 +108,7 @@ def _three_rank_case(group):
     crepe.DITHER = lambda n: torch.zeros(n)
     audio = vocal_like(1.995, 16000, 1240)
     outs = []
-    for method in ("rmvpe", "mangio-crepe"):
+    for method in ("mangio-crepe",):   # (rmvpe over two ranks: test_two_rank_sharding_matches_single_process)
         out = vc.pipeline(hub, net_g, 0, audio, "x.wav", [0, 0, 0], 0, method, "", 0.5, 1, 3, tgt_sr, 0, 0.25, "v2", 0.33, 64,
                           noise_fn=tp.noise_fn_for(nets), group=group)
         outs.append(out)
