@@ -103,6 +103,37 @@ __device__ __forceinline__ float4 buf_load_f32x4(const BufRsrc& r, unsigned voff
 #endif
 static constexpr unsigned kBufOob = 0x80000000u;  // any byte offset >= 2^31 is out of range for the buffers made here
 
+// ---- split-precision (bf16 hi + bf16 lo) helpers -----------------------------------------------------------------------------
+// x ~= hi + lo with hi = bf16(x) (round to nearest even) and lo = bf16(x - hi): 16 significand bits of x survive; products are
+// formed as hi*hi + hi*lo + lo*hi on the bf16 matrix pipe with fp32 accumulation (the lo*lo term, <= 2^-16 relative, is dropped).
+__device__ __forceinline__ unsigned bf16_rne_bits(float x) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;   // (finite inputs; NaN payloads are not preserved)
+}
+__device__ __forceinline__ void split_bf16(float x, unsigned& hi, unsigned& lo) {
+    hi = bf16_rne_bits(x);
+    lo = bf16_rne_bits(x - __builtin_bit_cast(float, hi << 16));
+}
+// 8 bf16 (k = 8 half .. 8 half + 7 of a 16-row K group) packed in a float4: element e in bits 16 (e & 1) of word e >> 1
+typedef float mfma_f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ mfma_f32x16 mfma_bf16_32x32x16(const float4& a, const float4& b, mfma_f32x16 c) {
+#ifdef AICG_EMULATED
+    const unsigned aw[4] = {__builtin_bit_cast(unsigned, a.x), __builtin_bit_cast(unsigned, a.y), __builtin_bit_cast(unsigned, a.z),
+                            __builtin_bit_cast(unsigned, a.w)};
+    const unsigned bw[4] = {__builtin_bit_cast(unsigned, b.x), __builtin_bit_cast(unsigned, b.y), __builtin_bit_cast(unsigned, b.z),
+                            __builtin_bit_cast(unsigned, b.w)};
+    for (int e = 0; e < 8; ++e) {   // 8 two-row contractions of the fp32 MFMA model: lane half h supplies k = 8 h + e
+        const float av = __builtin_bit_cast(float, (aw[e >> 1] >> (16 * (e & 1))) << 16);
+        const float bv = __builtin_bit_cast(float, (bw[e >> 1] >> (16 * (e & 1))) << 16);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, c, 0, 0, 0);
+    }
+    return c;
+#else
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#endif
+}
+
 // value of the lane whose id differs in bit 0 / bit 1 (exchange inside a quad of lanes): one DPP move on the hardware
 __device__ __forceinline__ float quad_xor1(float v) {
 #ifdef AICG_EMULATED

@@ -1,6 +1,6 @@
 // aicg_conv_forward: geometry checks, tile choice and launch of the implicit-GEMM convolution family (conv_kernels.h), plus
 // the pointwise streaming kernel for 1x1 layers with <= 8 channels on one side.
-#include "conv_ws3.h"
+#include "conv_ws3s.h"
 
 namespace aicg {
 
@@ -142,6 +142,7 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
     p.Cin_pad = idiv_up(p.Cin_g, 32) * 32;
     p.w_group_stride = (long)p.taps * p.Cin_pad * p.Mpad;
     p.w3 = d->packed_v3 ? w_packed + (long)p.groups * p.w_group_stride : nullptr;
+    p.wsplit = d->packed_v3 && d->split ? w_packed + 2L * p.groups * p.w_group_stride : nullptr;
 
     // pointwise streaming form: 1x1, unit stride, no padding, <= 8 channels on one side, float4-aligned rows
     {
@@ -200,6 +201,30 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
     auto blocks = [&](int bm, int bn) { return (long)idiv_up(M, bm) * p.groups * ldiv_up(npos, bn); };
     const long want = 512;
     static const int ws = getenv("AICG_CONV_WS") ? atoi(getenv("AICG_CONV_WS")) : 1;
+    // opt-in split precision (aicg_conv_desc.split, conv_ws3s.h): no 160-row tile there (5 x 16 accumulators leave no room for
+    // hi + lo fragments), those layers take the least-padded of the other tiles
+    if (p.wsplit && p.Cin_g >= 16 && M > 16 && !(M > 32 && M <= 48)) {
+        int bm = 32;
+        {
+            long best = 1L << 40;
+            const int cands[4] = {128, 96, 64, 32};
+            for (int i = 0; i < 4; ++i) {
+                const long padded = (long)idiv_up(M, cands[i]) * cands[i];
+                if (padded < best) { best = padded; bm = cands[i]; }
+            }
+        }
+        int rc = 1;
+        if (bm == 128 && blocks(128, 128) >= want) rc = run_ws3s_128x128(p, st);
+        else if (bm == 96 && blocks(96, 128) >= want) rc = run_ws3s_96x128(p, st);
+        else if (M > 32 && blocks(64, 128) >= want) rc = run_ws3s_64x128(p, st);
+        if (rc == 1) {
+            if (M > 32) {
+                if (!(blocks(64, 128) >= want) && (blocks(64, 64) >= want || M > 64)) rc = run_ws3s_64x64(p, st);
+            } else if (blocks(32, 256) >= want) rc = run_ws3s_32x256(p, st);
+            else rc = run_ws3s_32x128(p, st);
+        }
+        if (rc <= 0) return rc;
+    }
     // 16-byte-fragment kernels (conv_ws3.h): every tile except the 160-row one, layers with >= 8 input channels per group
     static const int v3 = getenv("AICG_CONV_V3") ? atoi(getenv("AICG_CONV_V3")) : 1;
     if (ws && v3 && p.w3 && p.Cin_g >= 8) {

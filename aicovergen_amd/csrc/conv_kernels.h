@@ -43,6 +43,7 @@ struct ConvArgs {
     const float* x;
     const float* w;
     const float* w3;   // k8-interleaved image of the same weights (conv_ws3.h), or nullptr
+    const float* wsplit;   // bf16 hi / lo image (conv_ws3s.h) when the layer runs in split precision, or nullptr
     const float* bias;
     const float* res;
     float* y;

@@ -143,16 +143,33 @@ class ConvDesc(ctypes.Structure):
                [("pre_act", ctypes.c_int32), ("pre_slope", ctypes.c_float), ("act", ctypes.c_int32),
                 ("act_slope", ctypes.c_float), ("out_scale", ctypes.c_float), ("accumulate", ctypes.c_int32),
                 ("res_before_act", ctypes.c_int32), ("pad_h_end", ctypes.c_int32), ("pad_w_end", ctypes.c_int32),
-                ("shuffle", ctypes.c_int32), ("res_mul", ctypes.c_int32), ("packed_v3", ctypes.c_int32)]
+                ("shuffle", ctypes.c_int32), ("res_mul", ctypes.c_int32), ("packed_v3", ctypes.c_int32),
+                ("split", ctypes.c_int32)]
 
 
 def conv_bkc(taps):
     return _lib.get().aicg_conv_bkc(int(taps))
 
 
-def pack_conv_weight(w, groups=1):
+# Opt-in split precision for the convolution family (AICG_PRECISION=bf16x3; default fp32 on the fp32 MFMA): layers packed while
+# this is set carry a third weight image and run csrc/conv_ws3s.h.  Read once at import; tests flip the module attribute.
+split_precision = os.environ.get("AICG_PRECISION", "fp32").lower() in ("bf16x3", "split")
+
+
+def _split_image(out):
+    """(groups, taps, Cin_pad, Mpad) fp32 -> the bf16 hi / lo image [tap][Cin_pad/16][hi|lo][h][Mpad][8], as fp32 words."""
+    g, taps, cpad, mpad = out.shape
+    hi = out.to(torch.bfloat16)                       # round to nearest even
+    lo = (out - hi.to(torch.float32)).to(torch.bfloat16)
+    both = torch.stack([hi, lo], 0)                   # (part, g, taps, cpad, mpad)
+    both = both.reshape(2, g, taps, cpad // 16, 2, 8, mpad).permute(1, 2, 3, 0, 4, 6, 5).contiguous()
+    return both.view(torch.int16).reshape(-1).view(torch.float32)
+
+
+def pack_conv_weight(w, groups=1, split=False):
     """(Cout, Cin/groups, KH, KW) -> two images back to back (pure re-layout + zero pad; Cin_pad and Mpad are multiples of
-    32): per group [tap][Cin_pad][Mpad], then per group [tap][Cin_pad/8][2][Mpad][4] (aicg_conv_desc.packed_v3)."""
+    32): per group [tap][Cin_pad][Mpad], then per group [tap][Cin_pad/8][2][Mpad][4] (aicg_conv_desc.packed_v3); with `split` a
+    third one of the same size, the bf16 hi / lo pairs of aicg_conv_desc.split."""
     w = w.detach().to(torch.float32)
     cout, cin_g, kh, kw = w.shape
     taps = kh * kw
@@ -164,7 +181,10 @@ def pack_conv_weight(w, groups=1):
     # second image for the 16-byte-fragment kernels (csrc/conv_ws3.h): input channel ci = 8 q + 2 j + parity is element j of the
     # quad at [tap][q][parity][m]
     v3 = out.reshape(groups, taps, cpad // 8, 4, 2, mpad).permute(0, 1, 2, 4, 5, 3)
-    return torch.cat([out.reshape(-1), v3.reshape(-1)]).contiguous()
+    parts = [out.reshape(-1), v3.reshape(-1)]
+    if split:
+        parts.append(_split_image(out))
+    return torch.cat(parts).contiguous()
 
 
 class PackedConv:
@@ -185,7 +205,8 @@ class PackedConv:
         self.groups = groups
         self.stride, self.padding, self.dilation = stride, padding, dilation
         device = weight.device if device is None else device
-        self.w = pack_conv_weight(weight.to(device), groups)
+        self.split = bool(split_precision)
+        self.w = pack_conv_weight(weight.to(device), groups, self.split)
         self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
 
     def out_hw(self, h, w):
@@ -274,6 +295,7 @@ def conv(x, pc, res=None, out=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NON
     d.pad_h_end, d.pad_w_end = (-1, -1) if pc.padding_end is None else pc.padding_end
     d.shuffle, d.res_mul = int(shuffle), 1 if res_mul else 0
     d.packed_v3 = 1
+    d.split = 1 if getattr(pc, "split", False) else 0
     prof = conv_profile
     if prof is not None and x.is_cuda:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

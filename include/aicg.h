@@ -113,6 +113,12 @@ typedef struct aicg_conv_desc {
                                      groups * KH*KW * Cin_pad * Mpad floats: the classic [tap][Cin_pad][Mpad] one and the
                                      k8-interleaved [tap][Cin_pad/8][2][Mpad][4] one (element j of a quad = input channel
                                      8 q + 2 j + parity) that the 16-byte-fragment kernels read */
+    int32_t split;                /* nonzero (needs packed_v3): opt-in split precision.  A third image of the same size follows,
+                                     [tap][Cin_pad/16][hi|lo][h][Mpad] x 8 bf16 (input channel 16 q + 8 h + e; w = hi + lo, hi =
+                                     bf16(w) round-to-nearest-even, lo = bf16(w - hi)); layers with >= 16 input channels per
+                                     group and > 48 or 17..32 output channels are then computed as hi*hi + hi*lo + lo*hi on the
+                                     bf16 matrix pipe with fp32 accumulation (csrc/conv_ws3s.h: ~1e-5 relative to the fp32
+                                     kernels); the other layers run the fp32 kernels unchanged */
 } aicg_conv_desc;
 
 int aicg_conv_bkc(int taps);
