@@ -23,6 +23,7 @@ def _freq_to_bin(freq, ceil=False):
 
 
 class Crepe:
+    @ops.fp32_only   # pitch-bin selection stays bit-exact under AICG_PRECISION=bf16x3
     def __init__(self, state_dict, device):
         sd = state_dict
         dev = torch.device(device)

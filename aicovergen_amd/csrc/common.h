@@ -114,6 +114,22 @@ __device__ __forceinline__ void split_bf16(float x, unsigned& hi, unsigned& lo) 
     hi = bf16_rne_bits(x);
     lo = bf16_rne_bits(x - __builtin_bit_cast(float, hi << 16));
 }
+// two values at once: word = bf16(v0) | bf16(v1) << 16 for the hi and the lo parts (v_cvt_pk_bf16_f32 on gfx950: 5 VALU ops a pair)
+__device__ __forceinline__ void split_bf16_pair(float v0, float v1, unsigned& hi, unsigned& lo) {
+#ifdef AICG_EMULATED
+    unsigned h0, l0, h1, l1;
+    split_bf16(v0, h0, l0);
+    split_bf16(v1, h1, l1);
+    hi = h0 | (h1 << 16);
+    lo = l0 | (l1 << 16);
+#else
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const bf16x2_t h = {(__bf16)v0, (__bf16)v1};
+    hi = __builtin_bit_cast(unsigned, h);
+    const bf16x2_t l = {(__bf16)(v0 - __builtin_bit_cast(float, hi << 16)), (__bf16)(v1 - __builtin_bit_cast(float, hi & 0xffff0000u))};
+    lo = __builtin_bit_cast(unsigned, l);
+#endif
+}
 // 8 bf16 (k = 8 half .. 8 half + 7 of a 16-row K group) packed in a float4: element e in bits 16 (e & 1) of word e >> 1
 typedef float mfma_f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ mfma_f32x16 mfma_bf16_32x32x16(const float4& a, const float4& b, mfma_f32x16 c) {

@@ -179,6 +179,34 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
     hipStream_t st = (hipStream_t)stream;
     static const int ablate = getenv("AICG_CONV_ABLATE") ? atoi(getenv("AICG_CONV_ABLATE")) : 0;
     p.dbg = ablate;
+    auto blocks = [&](int bm, int bn) { return (long)idiv_up(M, bm) * p.groups * ldiv_up(npos, bn); };
+    const long want = 512;
+    // opt-in split precision (aicg_conv_desc.split, conv_ws3s.h): no 160-row tile there (5 x 16 accumulators leave no room for
+    // hi + lo fragments), those layers take the least-padded of the other tiles
+    if (p.wsplit && p.Cin_g >= 16 && M > 16) {
+        int bm = 32;
+        {
+            long best = 1L << 40;
+            const int cands[4] = {128, 96, 64, 32};
+            for (int i = 0; i < 4; ++i) {
+                const long padded = (long)idiv_up(M, cands[i]) * cands[i];
+                if (padded < best) { best = padded; bm = cands[i]; }
+            }
+        }
+        int rc = 1;
+        if (bm == 128 && blocks(128, 128) >= want) rc = run_ws3s_128x128(p, st);
+        else if (bm == 96 && blocks(96, 128) >= want) rc = run_ws3s_96x128(p, st);
+        else if (M > 32 && blocks(64, 128) >= want) rc = run_ws3s_64x128(p, st);
+        if (rc == 1) {
+            if (M > 32) {
+                if (!(blocks(64, 128) >= want) && (blocks(64, 64) >= want || M > 64)) rc = run_ws3s_64x64(p, st);
+            } else {
+                if (blocks(32, 256) >= want) rc = run_ws3s_32x256(p, st);
+                if (rc == 1) rc = run_ws3s_32x128(p, st);   // (also: a 256-position patch too large to stage)
+            }
+        }
+        if (rc <= 0) return rc;
+    }
     // narrow layers (16 / 48 output channels, at least 3 input channels, enough positions): 16x16x4 MFMA tiles
     static const bool use16 = getenv("AICG_CONV_M16") ? atoi(getenv("AICG_CONV_M16")) != 0 : true;
     // (measured r2: MDX level 0 97 vs 105 TFLOP/s, RMVPE level 0 57 vs 60 against conv_ws16_kernel -- 12 MFMAs per k-step already
@@ -198,33 +226,7 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
     }
     // A launch should give each of the 256 CUs at least ~2 workgroups: shrink the tile for small problems
     // (HuBERT / enc_p GEMMs over a few thousand frames), M first (keeps the wide, coalesced N tile), then N.
-    auto blocks = [&](int bm, int bn) { return (long)idiv_up(M, bm) * p.groups * ldiv_up(npos, bn); };
-    const long want = 512;
     static const int ws = getenv("AICG_CONV_WS") ? atoi(getenv("AICG_CONV_WS")) : 1;
-    // opt-in split precision (aicg_conv_desc.split, conv_ws3s.h): no 160-row tile there (5 x 16 accumulators leave no room for
-    // hi + lo fragments), those layers take the least-padded of the other tiles
-    if (p.wsplit && p.Cin_g >= 16 && M > 16 && !(M > 32 && M <= 48)) {
-        int bm = 32;
-        {
-            long best = 1L << 40;
-            const int cands[4] = {128, 96, 64, 32};
-            for (int i = 0; i < 4; ++i) {
-                const long padded = (long)idiv_up(M, cands[i]) * cands[i];
-                if (padded < best) { best = padded; bm = cands[i]; }
-            }
-        }
-        int rc = 1;
-        if (bm == 128 && blocks(128, 128) >= want) rc = run_ws3s_128x128(p, st);
-        else if (bm == 96 && blocks(96, 128) >= want) rc = run_ws3s_96x128(p, st);
-        else if (M > 32 && blocks(64, 128) >= want) rc = run_ws3s_64x128(p, st);
-        if (rc == 1) {
-            if (M > 32) {
-                if (!(blocks(64, 128) >= want) && (blocks(64, 64) >= want || M > 64)) rc = run_ws3s_64x64(p, st);
-            } else if (blocks(32, 256) >= want) rc = run_ws3s_32x256(p, st);
-            else rc = run_ws3s_32x128(p, st);
-        }
-        if (rc <= 0) return rc;
-    }
     // 16-byte-fragment kernels (conv_ws3.h): every tile except the 160-row one, layers with >= 8 input channels per group
     static const int v3 = getenv("AICG_CONV_V3") ? atoi(getenv("AICG_CONV_V3")) : 1;
     if (ws && v3 && p.w3 && p.Cin_g >= 8) {

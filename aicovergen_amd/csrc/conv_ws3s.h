@@ -83,11 +83,7 @@ __device__ __forceinline__ void ws3s_produce(const ConvArgs& p, float* xs0, floa
                     float v0 = xv[e][k], v1 = xv[e][k + 1];
                     if (p.pre_act == AICG_ACT_LRELU) { v0 = v0 > 0.f ? v0 : v0 * p.pre_slope; v1 = v1 > 0.f ? v1 : v1 * p.pre_slope; }
                     else if (p.pre_act != AICG_ACT_NONE) { v0 = apply_act(v0, p.pre_act, p.pre_slope); v1 = apply_act(v1, p.pre_act, p.pre_slope); }
-                    unsigned h0b, l0b, h1b, l1b;
-                    split_bf16(v0, h0b, l0b);
-                    split_bf16(v1, h1b, l1b);
-                    hw[k >> 1] = h0b | (h1b << 16);
-                    lw[k >> 1] = l0b | (l1b << 16);
+                    split_bf16_pair(v0, v1, hw[k >> 1], lw[k >> 1]);
                 }
                 if (pdst[e] >= 0) {
                     xs[pdst[e]] = make_float4(__builtin_bit_cast(float, hw[0]), __builtin_bit_cast(float, hw[1]), __builtin_bit_cast(float, hw[2]),
@@ -246,8 +242,8 @@ static int launch_conv_ws3s(ConvArgs& p, hipStream_t stream) {
     p.xs_elems = (p.xs_total + 3) & ~3;
     p.div_chs = div_mul(p.CHS);
     p.div_twp = div_mul(p.TWp);
-    if (p.xs_total > 16 * 256) return 1;   // <= 2 items of 8 channels per producer thread
-    const int xi = idiv_up(p.xs_total / 8, 256) <= 1 ? 1 : 2;
+    if (p.xs_total > 24 * 256) return 1;   // <= 3 items of 8 channels per producer thread (3 only for 16-channel chunks of wide patches)
+    const int xi = imax(1, idiv_up(p.xs_total / 8, 256));
     const size_t lds = (size_t)(2 * 2 * xi * 256 * 4 + 2 * Ws3Geom<BM, KS>::WS_ELEMS) * sizeof(float);
     const bool off_ok = (long)(p.BKC + 8) * p.x_sc + (long)p.H * p.x_sh < (1L << 29) && (long)p.taps * p.Cin_pad * p.Mpad < (1L << 29);
     if (lds > 160 * 1024 || !off_ok || (long)p.xs_total * p.CHS >= (1L << 32)) return 1;
@@ -261,8 +257,10 @@ static int launch_conv_ws3s(ConvArgs& p, hipStream_t stream) {
         static const int wide = getenv("AICG_CONV_WIDE") ? atoi(getenv("AICG_CONV_WIDE")) : 1;
         p.wide_ok = wide && (size_t)(WM * WN) * kEpiScratch * sizeof(float) <= lds ? conv_wide_ok(p) : 0;
     }
-    auto kern = gen ? (xi == 1 ? conv_ws3s_kernel<BM, BN, WM, WN, 1, KS, true> : conv_ws3s_kernel<BM, BN, WM, WN, 2, KS, true>)
-                    : (xi == 1 ? conv_ws3s_kernel<BM, BN, WM, WN, 1, KS, false> : conv_ws3s_kernel<BM, BN, WM, WN, 2, KS, false>);
+    auto kern = gen ? (xi == 1 ? conv_ws3s_kernel<BM, BN, WM, WN, 1, KS, true>
+                       : xi == 2 ? conv_ws3s_kernel<BM, BN, WM, WN, 2, KS, true> : conv_ws3s_kernel<BM, BN, WM, WN, 3, KS, true>)
+                    : (xi == 1 ? conv_ws3s_kernel<BM, BN, WM, WN, 1, KS, false>
+                       : xi == 2 ? conv_ws3s_kernel<BM, BN, WM, WN, 2, KS, false> : conv_ws3s_kernel<BM, BN, WM, WN, 3, KS, false>);
     allow_dynamic_lds((const void*)kern, lds);
     hipLaunchKernelGGL(kern, grid, block, lds, stream, p);
     return check_launch("conv_ws3s_kernel");

@@ -1,6 +1,8 @@
 """Thin torch-tensor wrappers over the C ABI (include/aicg.h).  No arithmetic happens here: these
 functions validate shapes, allocate outputs with torch, and hand raw device pointers + the current HIP
 stream to libaicg_hip.so."""
+import contextlib
+import functools
 import math
 import os
 import threading
@@ -154,6 +156,27 @@ def conv_bkc(taps):
 # Opt-in split precision for the convolution family (AICG_PRECISION=bf16x3; default fp32 on the fp32 MFMA): layers packed while
 # this is set carry a third weight image and run csrc/conv_ws3s.h.  Read once at import; tests flip the module attribute.
 split_precision = os.environ.get("AICG_PRECISION", "fp32").lower() in ("bf16x3", "split")
+
+
+@contextlib.contextmanager
+def fp32_layers():
+    """Layers packed inside this block stay on the fp32 MFMA whatever AICG_PRECISION says: the f0 estimators and the retrieval
+    search select INDICES (pitch bins, neighbour ids), which are kept bit-exact (BASELINE north_star)."""
+    global split_precision
+    old, split_precision = split_precision, False
+    try:
+        yield
+    finally:
+        split_precision = old
+
+
+def fp32_only(fn):
+    """Decorator form of fp32_layers for constructors."""
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        with fp32_layers():
+            return fn(*a, **k)
+    return wrapped
 
 
 def _split_image(out):
@@ -592,8 +615,8 @@ def linear_last(x, weight, bias=None, ch_scale=None, ch_shift=None, act=ACT_NONE
     if res is not None:
         assert res.is_contiguous() and res.shape == out.shape
     _check(x, weight, bias, ch_scale, ch_shift, res, out)
-    _call("aicg_gemm_nt", _ptr(x), _ptr(weight), _ptr(bias), _ptr(ch_scale), _ptr(ch_shift), _ptr(res), _ptr(out),
-              b * c * t, f, o, f, f, o, o, t, c, act, _stream(x))
+    _call("aicg_gemm_nt_split" if split_precision else "aicg_gemm_nt", _ptr(x), _ptr(weight), _ptr(bias), _ptr(ch_scale),
+          _ptr(ch_shift), _ptr(res), _ptr(out), b * c * t, f, o, f, f, o, o, t, c, act, _stream(x))
     return out
 
 

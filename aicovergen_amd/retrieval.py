@@ -34,7 +34,8 @@ class FeatureIndex:
         """feats (T, dim) float32 device -> (squared distances (T, 8) ascending, ids (T, 8) int64)."""
         t = feats.shape[0]
         feats = feats.contiguous().float()
-        pc = ops.PackedConv(feats.unsqueeze(-1), None, device=feats.device)   # queries as the GEMM's rows
+        with ops.fp32_layers():   # neighbour ids are an index selection: always the fp32 kernels
+            pc = ops.PackedConv(feats.unsqueeze(-1), None, device=feats.device)   # queries as the GEMM's rows
         qnorm = ops.row_sqnorm(feats)
         best_d = torch.empty((t, 8), dtype=torch.float32, device=feats.device)
         best_i = torch.empty((t, 8), dtype=torch.int64, device=feats.device)

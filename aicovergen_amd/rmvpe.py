@@ -83,6 +83,7 @@ class MelSpectrogram:
         self._pc = None
         return self
 
+    @ops.fp32_only
     def __call__(self, audio, keyshift=0, speed=1, center=True):
         assert keyshift == 0 and speed == 1 and center, "only the configuration RMVPE.infer_from_audio uses"
         if self._pc is None:
@@ -96,6 +97,7 @@ class MelSpectrogram:
 class E2E:
     """rmvpe.E2E.forward (src/rmvpe.py:254-258) from the reference state_dict."""
 
+    @ops.fp32_only   # pitch-bin selection stays bit-exact under AICG_PRECISION=bf16x3
     def __init__(self, sd, device):
         dev = torch.device(device)
         self.device = dev

@@ -116,7 +116,7 @@ typedef struct aicg_conv_desc {
     int32_t split;                /* nonzero (needs packed_v3): opt-in split precision.  A third image of the same size follows,
                                      [tap][Cin_pad/16][hi|lo][h][Mpad] x 8 bf16 (input channel 16 q + 8 h + e; w = hi + lo, hi =
                                      bf16(w) round-to-nearest-even, lo = bf16(w - hi)); layers with >= 16 input channels per
-                                     group and > 48 or 17..32 output channels are then computed as hi*hi + hi*lo + lo*hi on the
+                                     group and more than 16 output channels are then computed as hi*hi + hi*lo + lo*hi on the
                                      bf16 matrix pipe with fp32 accumulation (csrc/conv_ws3s.h: ~1e-5 relative to the fp32
                                      kernels); the other layers run the fp32 kernels unchanged */
 } aicg_conv_desc;
@@ -224,6 +224,11 @@ int aicg_f0_coarse(const double* f0_in, double factor, double* f0_out, int64_t* 
 int aicg_gemm_nt(const float* a, const float* w, const float* bias, const float* row_scale,
                  const float* row_shift, const float* res, float* c, int64_t R, int K, int O, int64_t lda,
                  int64_t ldw, int64_t ldc, int64_t ldr, int rows_per_ch, int n_ch, int act, void* stream);
+/* the same contract in the opt-in split precision (both operands carried as bf16 hi + lo, products hi*hi + hi*lo + lo*hi on the
+ * bf16 matrix pipe, fp32 accumulation and epilogue; ~4e-6 relative to aicg_gemm_nt -- see aicg_conv_desc.split) */
+int aicg_gemm_nt_split(const float* a, const float* w, const float* bias, const float* row_scale,
+                       const float* row_shift, const float* res, float* c, int64_t R, int K, int O, int64_t lda,
+                       int64_t ldw, int64_t ldc, int64_t ldr, int rows_per_ch, int n_ch, int act, void* stream);
 /* out = a * b elementwise (U-Net skip connection of the TFC-TDF net: x *= ds_outputs[-i-1]) */
 int aicg_mul(const float* a, const float* b, float* out, int64_t n, void* stream);
 /* run_mdx epilogue pieces (src/mdx.py:259-267,280): out = alpha * a + beta * b (+ gamma * c if c) */

@@ -22,6 +22,8 @@ CASES = [
     (130, 200, 3, 1, 1, 1, 1, 70),    # channels not multiples of anything
     (96, 96, 16, 1, 8, 1, 4, 130),    # grouped, 24 channels per group
     (32, 32, 3, 2, 0, 1, 1, 301),     # strided
+    (48, 48, 3, 1, 1, 1, 1, 300),     # 48 rows (MDX level 0) on the 64-row tile
+    (32, 64, 3, 2, 0, 1, 1, 601),     # stride 2 over a 128-position tile: 257-position patch, three 8-channel items per thread
 ]
 
 
@@ -85,3 +87,27 @@ def test_default_is_fp32():
         w = torch.randn(32, 32, 3)
         assert ops.pack_conv_weight(w.unsqueeze(2)).numel() == 2 * 3 * 32 * 32
         assert ops.pack_conv_weight(w.unsqueeze(2), split=True).numel() == 3 * 3 * 32 * 32
+
+
+@pytest.mark.parametrize("R,K,O", [(300, 64, 40), (515, 100, 130), (128, 36, 256), (256, 384, 128)])
+def test_gemm_nt_split(dev, R, K, O):
+    """aicg_gemm_nt_split: the TDF linear in split precision, ragged rows / K tail inside an 8-chunk / output tile, fused epilogue;
+    (256, 384, 128) with 32-row channels takes the float4 epilogue."""
+    from aicovergen_amd import _lib
+    torch.manual_seed(R + K)
+    if dev.big:
+        R = R * 40 + (3 if R != 256 else 0)
+    n_ch, rows_per_ch = (5, 7) if R % 128 else (4, 32)
+    x = torch.randn(R, K)
+    w, b = torch.randn(O, K) * 0.2, torch.randn(O)
+    sc, sh = torch.rand(n_ch) + 0.5, torch.randn(n_ch)
+    res = torch.randn(R, O)
+    ch = (torch.arange(R) // rows_per_ch) % n_ch
+    ref = torch.relu((x.double() @ w.double().t() + b) * sc[ch, None] + sh[ch, None]).float() + res
+    o = dev.t(torch.empty(R, O))
+    xd, wd, bd, scd, shd, rd = (dev.t(t) for t in (x, w, b, sc, sh, res))
+    st = torch.cuda.current_stream().cuda_stream if dev.kind == "hip" else 0
+    _lib.call("aicg_gemm_nt_split", xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), scd.data_ptr(), shd.data_ptr(), rd.data_ptr(),
+              o.data_ptr(), R, K, O, K, K, O, O, rows_per_ch, n_ch, ops.ACT_RELU, st)
+    err = rel_rms(o, ref)
+    assert err < TOL, err
