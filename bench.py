@@ -35,6 +35,8 @@ sys.path.insert(0, ROOT)
 
 TRACK_S = 240.0
 PEAK_F32_MFMA = 157.3   # TFLOP/s, MI355X_MICROARCH.md
+PEAK_BF16_MFMA = 2516.6  # TFLOP/s dense (16 x the fp32 MFMA rate, MI355X_MICROARCH.md "1/16 of BF16 MFMA")
+MFMA_PEAK = PEAK_F32_MFMA  # of the arithmetic in use: --precision bf16x3 spends three bf16 MFMAs per fp32 product -> bf16 / 3
 PEAK_HBM = 8000.0       # GB/s spec (6290 measured float4 copy)
 
 
@@ -145,14 +147,14 @@ def pmc_traffic_per_launch():
 def stage_table(conv, stages, steps):
     """Per-stage roofline fractions (report per stage; STFT / iSTFT stand-alone)."""
     rows = [{"stage": "conv family (implicit GEMM)", "bound": "mfma", "ms_per_step": conv["ms"] / steps,
-             "achieved": conv["tflops"], "unit": "TFLOP/s", "frac": conv["tflops"] / PEAK_F32_MFMA}]
+             "achieved": conv["tflops"], "unit": "TFLOP/s", "frac": conv["tflops"] / MFMA_PEAK}]
     for name, r in sorted(stages.items(), key=lambda kv: -kv[1]["ms"]):
         if r["ms"] <= 0:
             continue
         if r["flops"] > 0:
             a = r["flops"] / (r["ms"] * 1e-3) / 1e12
             rows.append({"stage": name, "bound": "mfma", "ms_per_step": r["ms"] / steps, "achieved": a, "unit": "TFLOP/s",
-                         "frac": a / PEAK_F32_MFMA})
+                         "frac": a / (MFMA_PEAK if name == "tdf_gemm_nt" else PEAK_F32_MFMA)})
         else:
             a = r["bytes"] / (r["ms"] * 1e-3) / 1e9
             rows.append({"stage": name, "bound": "hbm", "ms_per_step": r["ms"] / steps, "achieved": a, "unit": "GB/s",
@@ -168,6 +170,9 @@ def main():
     ap.add_argument("--config", choices=["C2", "C3", "C4", "C5"], default="C3")
     ap.add_argument("--mdx-models", type=int, default=1, choices=[1, 3])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default=None,
+                    help="arithmetic of the conv / TDF GEMM family: fp32 MFMA (default, the headline) or the opt-in split precision "
+                         "(bf16 hi + lo operands, 3 bf16 MFMAs per product, fp32 accumulation); default: $AICG_PRECISION or fp32")
     ap.add_argument("--track-seconds", type=float, default=None)
     ap.add_argument("--dump", type=str, default=None, help="write the last step's outputs (npz) for cross-checking runs")
     args = ap.parse_args()
@@ -192,6 +197,11 @@ def main():
 
     from aicovergen_amd import ops
     from synthetic.inputs import song_like
+    global MFMA_PEAK
+    if args.precision is not None:
+        ops.split_precision = args.precision == "bf16x3"
+    split_mode = bool(ops.split_precision)
+    MFMA_PEAK = PEAK_BF16_MFMA / 3.0 if split_mode else PEAK_F32_MFMA
     strong = args.config == "C5"
     if strong:
         seconds = args.track_seconds or 1800.0        # one track in total, sharded over the ranks
@@ -246,7 +256,8 @@ def main():
             "metric": "real-time factor (audio-sec/wall-sec) for MDX+RVC on 4-min 44.1 kHz track",
             "value": seconds * args.steps / dt, "unit": "x real-time", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong" if strong else "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16x3 (bf16 hi+lo operands, f32 accumulate; f0 / kNN f32)" if split_mode else "f32",
+            "data": "synthetic",
             "config": {"workload": workload, "config_id": args.config, "mdx_models": args.mdx_models,
                        "audio_seconds_total": seconds, "rvc_preset": "x_pad,x_query,x_center,x_max=3,10,60,65",
                        "stage_handover": "device (aicg_resample_poly); excluded like in the reference's metric: model load, WAV "
@@ -255,13 +266,15 @@ def main():
                        "stage_seconds_per_step": {"hubert": stage[0] / args.steps, "f0": stage[1] / args.steps,
                                                   "synth": stage[2] / args.steps},
                        "wall_split_seconds_per_step": split},
-            "roofline": {"bound": "mfma", "achieved": conv["tflops"], "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
-                         "frac": conv["tflops"] / PEAK_F32_MFMA,
+            "roofline": {"bound": "mfma", "achieved": conv["tflops"], "peak": MFMA_PEAK, "unit": "TFLOP/s",
+                         "frac": conv["tflops"] / MFMA_PEAK,
                          "traffic": None if traffic is None else traffic["fetch_x2"],
                          "traffic_unit": None if traffic is None else
                          "HBM bytes per launch: rocprofv3 2 x FETCH_SIZE + WRITE_SIZE (%s); uncorrected %.4g" % (traffic["source"],
                                                                                                                 traffic["raw"]),
-                         "kernel": "conv family (fp32 MFMA implicit GEMM: conv_ws3 / conv_ws / conv_ws16 / conv_mfma)",
+                         "kernel": "conv family (fp32 MFMA implicit GEMM: conv_ws3 / conv_ws / conv_ws16 / conv_mfma)" if not split_mode
+                         else "conv family (split precision: conv_ws3s on the bf16 MFMA, 3 MFMAs per product -- achieved and peak are "
+                              "in fp32-equivalent TFLOP/s, peak = 2516.6 / 3; the f0 models' layers run the fp32 kernels)",
                          "launches_per_step": conv["launches"] / args.steps,
                          "algorithmic_tflop_per_step": conv["flops"] / args.steps / 1e12,
                          "algorithmic_bytes_per_launch": conv["bytes"] / max(1, conv["launches"]),

@@ -1,7 +1,3 @@
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_conv_split.py tests/test_kernels_misc.py -x -q -m gpu 2>&1 | tail -3
-timeout 300 python tools/kbench_tdf.py 2>&1 | tail -7
-AICG_PRECISION=bf16x3 timeout 300 python tools/kbench_tdf.py 2>&1 | tail -7
-AICG_PRECISION=bf16x3 timeout 120 python tools/kbench_one.py 48 48 3 1 4000000 2>&1 | tail -1
-timeout 120 python tools/kbench_one.py 48 48 3 1 4000000 2>&1 | tail -1
-AICG_PRECISION=bf16x3 timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>gpurun_out/split_bench.err | tee gpurun_out/split_bench3.json | cut -c1-300
+timeout 1500 python -m pytest tests/test_split_e2e.py -q -m gpu -s 2>&1 | grep -v "gin_channels\|^  frame" | tail -25
+timeout 900 python bench.py --steps 2 --warmup 1 --precision bf16x3 2>gpurun_out/split_bench.err | tee gpurun_out/split_bench4.json | cut -c1-300
