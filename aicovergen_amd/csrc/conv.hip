@@ -180,7 +180,8 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
     static const int ablate = getenv("AICG_CONV_ABLATE") ? atoi(getenv("AICG_CONV_ABLATE")) : 0;
     p.dbg = ablate;
     auto blocks = [&](int bm, int bn) { return (long)idiv_up(M, bm) * p.groups * ldiv_up(npos, bn); };
-    const long want = 512;
+    // (AICG_CONV_WANT: tests lower the fill target so that small problems exercise the large tiles on the CPU emulator)
+    static const long want = getenv("AICG_CONV_WANT") ? atol(getenv("AICG_CONV_WANT")) : 512;
     // opt-in split precision (aicg_conv_desc.split, conv_ws3s.h): no 160-row tile there (5 x 16 accumulators leave no room for
     // hi + lo fragments), those layers take the least-padded of the other tiles
     if (p.wsplit && p.Cin_g >= 16 && M > 16) {
@@ -194,9 +195,14 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
             }
         }
         int rc = 1;
+        // (measured: 64 x 256 with 2 x 2 tiles per consumer wave -- 12 MFMAs per 8 fragment reads -- beats 64 x 128 by 10-25 % on the
+        //  64-channel vocoder stage; the same wave shape on the 128-row tile loses 3 % to the 4 x 1 one)
         if (bm == 128 && blocks(128, 128) >= want) rc = run_ws3s_128x128(p, st);
         else if (bm == 96 && blocks(96, 128) >= want) rc = run_ws3s_96x128(p, st);
-        else if (M > 32 && blocks(64, 128) >= want) rc = run_ws3s_64x128(p, st);
+        else if (M > 32) {
+            if (blocks(64, 256) >= want) rc = run_ws3s_64x256(p, st);
+            if (rc == 1 && blocks(64, 128) >= want) rc = run_ws3s_64x128(p, st);
+        }
         if (rc == 1) {
             if (M > 32) {
                 if (!(blocks(64, 128) >= want) && (blocks(64, 64) >= want || M > 64)) rc = run_ws3s_64x64(p, st);

@@ -273,5 +273,6 @@ int run_ws3s_64x128(ConvArgs& p, hipStream_t st);
 int run_ws3s_64x64(ConvArgs& p, hipStream_t st);
 int run_ws3s_32x256(ConvArgs& p, hipStream_t st);
 int run_ws3s_32x128(ConvArgs& p, hipStream_t st);
+int run_ws3s_64x256(ConvArgs& p, hipStream_t st);      // 4 consumers x (64 x 64): 12 MFMAs per 8 fragment reads
 
 }  // namespace aicg

@@ -6,4 +6,5 @@ int run_ws3s_64x128(ConvArgs& p, hipStream_t st) { return launch_conv_ws3s<64, 1
 int run_ws3s_64x64(ConvArgs& p, hipStream_t st) { return launch_conv_ws3s<64, 64, 2, 2, 64>(p, st); }
 int run_ws3s_32x256(ConvArgs& p, hipStream_t st) { return launch_conv_ws3s<32, 256, 1, 4, 64>(p, st); }
 int run_ws3s_32x128(ConvArgs& p, hipStream_t st) { return launch_conv_ws3s<32, 128, 1, 4, 64>(p, st); }
+int run_ws3s_64x256(ConvArgs& p, hipStream_t st) { return launch_conv_ws3s<64, 256, 1, 4, 32>(p, st); }
 }  // namespace aicg

@@ -16,6 +16,7 @@ TOL = 3e-5
 CASES = [
     (32, 32, 3, 1, 1, 1, 1, 300),     # 32-row tile
     (64, 64, 7, 1, 9, 3, 1, 260),     # 64-row tile, dilated taps
+    (64, 64, 3, 1, 1, 1, 1, 2100),    # enough positions for the 64 x 256 tile (2 x 2 MFMA tiles per wave, single fragment set)
     (48, 96, 11, 1, 25, 5, 1, 200),   # 96-row tile, 48 channels = 3 groups of 16
     (192, 384, 5, 1, 2, 1, 1, 150),   # 128-row tile
     (40, 480, 3, 1, 1, 1, 1, 170),    # 480 rows: 96-row tiles here (the fp32 path takes 160), channel tail inside a 16-group
@@ -111,3 +112,27 @@ def test_gemm_nt_split(dev, R, K, O):
               o.data_ptr(), R, K, O, K, K, O, O, rows_per_ch, n_ch, ops.ACT_RELU, st)
     err = rel_rms(o, ref)
     assert err < TOL, err
+
+
+def test_large_split_tiles_on_the_emulator():
+    """With the fill target lowered (AICG_CONV_WANT=1) small problems take the tiles the bench sizes take: 128 x 128, 96 x 128,
+    64 x 256 (single fragment set), 32 x 256, with ragged last tiles, a channel tail and the 2-D halo."""
+    from test_conv import _run_child
+    code = r'''
+ops.split_precision = True
+for (ci, co, k, d, T) in [(48, 128, 5, 1, 300), (40, 96, 3, 3, 200), (64, 64, 7, 1, 600), (32, 32, 3, 1, 520), (144, 144, 3, 1, 150)]:
+    x = torch.randn(1, ci, T)
+    w = torch.randn(co, ci, k) * 0.1
+    b, r = torch.randn(co), torch.randn(1, co, T)
+    pc = ops.PackedConv(w, b, padding=(k - 1) * d // 2, dilation=d)
+    y = ops.conv(x, pc, act=ops.ACT_RELU, res=r)
+    e = rel(y, F.relu(F.conv1d(x, w, b, padding=(k - 1) * d // 2, dilation=d)) + r)
+    assert 1e-7 < e < 3e-5, (ci, co, k, d, T, e)
+x = torch.randn(2, 48, 20, 70)
+w = torch.randn(48, 48, 3, 3) * 0.1
+pc = ops.PackedConv(w, None, padding=1)
+e = rel(ops.conv(x, pc), F.conv2d(x, w, None, padding=1))
+assert 1e-7 < e < 3e-5, e
+print("large split tiles ok")
+'''
+    _run_child(code, {"AICG_CONV_WANT": "1"}, "large split tiles ok")
