@@ -123,11 +123,10 @@ __device__ __forceinline__ void split_bf16_pair(float v0, float v1, unsigned& hi
     hi = h0 | (h1 << 16);
     lo = l0 | (l1 << 16);
 #else
-    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-    const bf16x2_t h = {(__bf16)v0, (__bf16)v1};
-    hi = __builtin_bit_cast(unsigned, h);
-    const bf16x2_t l = {(__bf16)(v0 - __builtin_bit_cast(float, hi << 16)), (__bf16)(v1 - __builtin_bit_cast(float, hi & 0xffff0000u))};
-    lo = __builtin_bit_cast(unsigned, l);
+    // five VALU ops a pair (the (__bf16) casts compiled to a second, redundant conversion for the hi << 16 term)
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(hi) : "v"(v0), "v"(v1));
+    const float d0 = v0 - __builtin_bit_cast(float, hi << 16), d1 = v1 - __builtin_bit_cast(float, hi & 0xffff0000u);
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(lo) : "v"(d0), "v"(d1));
 #endif
 }
 // 8 bf16 (k = 8 half .. 8 half + 7 of a 16-row K group) packed in a float4: element e in bits 16 (e & 1) of word e >> 1

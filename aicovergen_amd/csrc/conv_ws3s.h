@@ -58,6 +58,7 @@ __device__ __forceinline__ void ws3s_produce(const ConvArgs& p, float* xs0, floa
         }
     }
     const unsigned ch1 = 4u * (unsigned)p.x_sc;   // byte distance of two channels
+    const bool lrelu_max = p.pre_act == AICG_ACT_LRELU && p.pre_slope >= 0.f && p.pre_slope <= 1.f;
     auto load = [&](int c, int tap0, float4 (&wv)[WR], float (&xv)[XI][8]) {
         const long wbase = ((long)tap0 * (p.Cin_pad >> 2) + (long)c * (p.BKC >> 2)) * p.Mpad * 4;
         const BufRsrc wb = make_buf(wg + wbase, (unsigned)lmin(((long)p.taps * p.Cin_pad * p.Mpad - wbase - (long)m_base * 4) * 4, 0x7fffffffL));
@@ -81,7 +82,10 @@ __device__ __forceinline__ void ws3s_produce(const ConvArgs& p, float* xs0, floa
 #pragma unroll
                 for (int k = 0; k < 8; k += 2) {
                     float v0 = xv[e][k], v1 = xv[e][k + 1];
-                    if (p.pre_act == AICG_ACT_LRELU) { v0 = v0 > 0.f ? v0 : v0 * p.pre_slope; v1 = v1 > 0.f ? v1 : v1 * p.pre_slope; }
+                    // (0 <= slope <= 1: lrelu(v) = max(v, slope v), same bits for every finite v, one VALU op less -- a producer wave
+                    //  gets about one VALU issue slot per MFMA while the consumers keep the matrix pipe busy)
+                    if (lrelu_max) { v0 = fmaxf(v0, v0 * p.pre_slope); v1 = fmaxf(v1, v1 * p.pre_slope); }
+                    else if (p.pre_act == AICG_ACT_LRELU) { v0 = v0 > 0.f ? v0 : v0 * p.pre_slope; v1 = v1 > 0.f ? v1 : v1 * p.pre_slope; }
                     else if (p.pre_act != AICG_ACT_NONE) { v0 = apply_act(v0, p.pre_act, p.pre_slope); v1 = apply_act(v1, p.pre_act, p.pre_slope); }
                     split_bf16_pair(v0, v1, hw[k >> 1], lw[k >> 1]);
                 }
@@ -149,14 +153,29 @@ __global__ void __launch_bounds__(64 * (WM * WN + 4), (WM * WN == 4 ? 4 : 3)) co
         const int jh = nl >> p.TWlog2, jw = nl & (p.TW - 1);
         boff[j] = jh * p.sh * p.TWp + jw * p.sw + half * p.CHS;
     }
+#ifdef AICG_CONV_TRACE
+    const int trace_wg = (wave == 0 && blockIdx.y == 0 && blockIdx.z == 0) ? (int)blockIdx.x : (1 << 30);
+    trace_mark(trace_wg, 0);
+    trace_val(trace_wg, 5, __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));   // HW_REG_HW_ID
+#else
+    const int trace_wg = 0;
+#endif
+    trace_mark(trace_wg, 6);
     f32x16 acc[TM][TN];
     ws_init_acc32<TM, TN>(p, acc, g, m_base + wm * (TM * 32), half);
     const int a_off = wm * (TM * 32) + l31 + half * BM;
+#ifdef AICG_CONV_TRACE
+    if (acc[0][0][0] == 1.2345e-30f) return;
+#endif
+    trace_mark(trace_wg, 7);
     {
         int c = 0, tap0 = 0;
         const int gpt = p.BKC >> 4;   // 16-channel groups per tap
         for (int st = 0; st < nstages; ++st) {
+            trace2(trace_wg, 0, st, 0);
             lds_barrier();
+            trace2(trace_wg, 0, st, 1);
+            if (st == 0) trace_mark(trace_wg, 1);
             const float4* xs = reinterpret_cast<const float4*>(xs0 + (c & 1) * XS_ELEMS);
             const float4* wt = reinterpret_cast<const float4*>(ws0 + (st & 1) * WS_ELEMS) + a_off;
             const int nt = imin(p.TT, p.taps - tap0);
@@ -207,6 +226,7 @@ __global__ void __launch_bounds__(64 * (WM * WN + 4), (WM * WN == 4 ? 4 : 3)) co
             if (tap0 >= p.taps) { tap0 = 0; ++c; }
         }
     }
+    trace_mark(trace_wg, 2);
     const bool interior = m_base + BM <= p.Cout_g && h0 + p.TH <= p.Ho && w0 + p.TW <= p.Wo;
     if (!GEN && interior && p.wide_ok) {
         lds_barrier();
@@ -214,6 +234,8 @@ __global__ void __launch_bounds__(64 * (WM * WN + 4), (WM * WN == 4 ? 4 : 3)) co
     } else {
         ws_epilogue32<TM, TN, GEN>(p, acc, n, g, m_base + wm * (TM * 32), wn * (TN * 32), h0, w0, l31, half, interior);
     }
+    trace_mark(trace_wg, 3);
+    trace_val(trace_wg, 4, (unsigned long long)nstages);
 }
 
 // returns 0 launched, < 0 error, 1 the configuration does not fit this form

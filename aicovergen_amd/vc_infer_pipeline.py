@@ -352,7 +352,11 @@ class VC(object):
             # would strand RMVPE's working set (a few GB for a 4-minute track) in up to 32 pools
             side = getattr(self, "_f0_stream", None)
             if side is None:
-                side = self._f0_stream = torch.cuda.Stream(device=self.device)
+                # high priority: the f0 branch is a short U-Net followed by a 70 ms recurrence on four CUs; dispatched first it
+                # leaves the chip to HuBERT while the GRU runs, dispatched behind HuBERT's launches it finishes 40 ms later
+                # (AICG_F0_PRIORITY=0: default priority)
+                prio = -1 if os.environ.get("AICG_F0_PRIORITY", "1") != "0" else 0
+                side = self._f0_stream = torch.cuda.Stream(device=self.device, priority=prio)
             # one upload of the padded track: a pageable host->device copy on the default stream waits for the whole device,
             # side stream included, so the chunk loop below must not issue any
             pad_dev = audio_pad.float()

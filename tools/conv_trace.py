@@ -89,6 +89,7 @@ def run(name, n, ci, co, H, W, k=3, d=1, mfma_per_kstep=None):
 
 if __name__ == "__main__":
     run("mdx_L1_c96 (96x128 tile, 3 MFMA/kstep, 432 ksteps -> floor 82944 cyc)", 16, 96, 96, 128, 1536)
+    run("rb_c256_k7 (1-D, 128x128 tile)", 1, 256, 256, 1, 400000, k=7)
     if len(sys.argv) > 1 and sys.argv[1] == "all":
         run("mdx_L2_c144 (160x128 tile)", 16, 144, 144, 64, 768)
         run("rb_c128_k7_d3 (1-D)", 1, 128, 128, 1, 660000, k=7, d=3)
