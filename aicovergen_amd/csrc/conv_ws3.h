@@ -98,6 +98,17 @@ __device__ __forceinline__ void ws3_produce(const ConvArgs& p, float* xs0, float
             if (p.pre_act == AICG_ACT_NONE) {
 #pragma unroll
                 for (int e = 0; e < XQ; ++e) *reinterpret_cast<float4*>(xs + e * PNT * 4) = xv[e];
+            } else if (p.pre_act == AICG_ACT_LRELU && p.pre_slope >= 0.f && p.pre_slope <= 1.f) {
+                // lrelu(v) = max(v, slope v) for 0 <= slope <= 1 (same bits for every finite v): a multiply and a max instead of
+                // compare + multiply + select -- producer VALU slots are scarce while the consumers keep the matrix pipe busy
+                const float sl = p.pre_slope;
+#pragma unroll
+                for (int e = 0; e < XQ; ++e) {
+                    float4 v = xv[e];
+                    v.x = fmaxf(v.x, v.x * sl); v.y = fmaxf(v.y, v.y * sl);
+                    v.z = fmaxf(v.z, v.z * sl); v.w = fmaxf(v.w, v.w * sl);
+                    *reinterpret_cast<float4*>(xs + e * PNT * 4) = v;
+                }
             } else if (p.pre_act == AICG_ACT_LRELU) {
                 const float sl = p.pre_slope;
 #pragma unroll

@@ -216,6 +216,9 @@ __global__ void __launch_bounds__(64 * (WM * WN + 4), (WM * WN == 4 ? 4 : 3)) co
                 }
                 if (s < ngroups) mma(f0);
             } else {
+                // (measured: reloading the A fragments row by row behind their MFMAs with the B fragments a k-step ahead -- no k-step
+                //  waiting for its own reads -- changes nothing: the second workgroup's wave on the SIMD already fills those gaps,
+                //  and the split kernels run at the chip's power limit)
                 Frag f0;
                 for (int s = 0; s < ngroups; ++s) {
                     fetch(f0, s);
