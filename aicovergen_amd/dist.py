@@ -5,10 +5,11 @@ parallel over fixed-size work items, so the only collective is the join:
   * MDX: the flattened (segment, window) list is cut into `world` contiguous slices; each rank separates its slice
     and one all_gather of equal-size (per, 2, gen) blocks rebuilds the window list on every rank (30-min stereo
     track: 635 MB total, 79 MB per peer link -- bandwidth-trivial on 7 x 153 GB/s xGMI links);
-  * RVC: `vc()` chunks are round-robined over ranks and joined by a length exchange + padded all_gather.  The cut search and the
-    RMVPE f0 of the whole track are computed redundantly on every rank: both are deterministic, the cut search is a few
-    milliseconds, and RMVPE's BiGRU is one sequential recurrence over the track that no rank can shorten (a broadcast from one
-    rank would leave the others idle for the same time).  CREPE's per-frame network is sharded over the ranks (crepe.predict).
+  * RVC: `vc()` chunks are round-robined over ranks and joined by a length exchange + padded all_gather.  The cut search is
+    computed redundantly on every rank (deterministic, a few milliseconds).  The f0 estimators are cut where they can be: CREPE's
+    per-frame network over frame slices (crepe.predict), RMVPE's U-Net over time segments with an exact context margin
+    (rmvpe.E2E.features_sharded), each joined by one all_gather; RMVPE's BiGRU is one sequential recurrence over the track that no
+    rank can shorten, so every rank runs it in full (a broadcast from one rank would leave the others idle for the same time).
 
 With world_size == 1 (or no initialised process group) every function degenerates to the single-GPU path, so the
 same code is exercised by the 1-GPU tests.

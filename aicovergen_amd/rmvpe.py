@@ -130,8 +130,8 @@ class E2E:
         self.bhh = torch.cat([sd["fc.0.gru.bias_hh_l0"], sd["fc.0.gru.bias_hh_l0_reverse"]]).float().contiguous().to(dev)
         self.fc = ops.PackedConv(sd["fc.1.weight"].float(), sd["fc.1.bias"], device=dev)
 
-    def __call__(self, mel, two_workgroups=None):
-        """mel (1, 128, T) with T % 32 == 0 -> salience (1, T, 360)."""
+    def features(self, mel):
+        """mel (1, 128, T) with T % 32 == 0 -> U-Net + cnn output (384, T), row c*128 + f: the BiGRU's input sequence."""
         T = mel.shape[-1]
         x = mel[0].t().contiguous().view(1, 1, T, mel.shape[1])          # mel.transpose(-1,-2).unsqueeze(1)
         x = ops.channel_affine(x, self.in_scale, self.in_shift)
@@ -155,8 +155,51 @@ class E2E:
             for blk in blocks:
                 x = blk(x)
         y = ops.conv(x, self.cnn)                                        # (1, 3, T, 128)
-        feat = y[0].permute(0, 2, 1).reshape(1, -1, T)                   # (1, 384, T): row c*128 + f
-        gi = ops.conv(feat.contiguous(), self.gru_in)                    # (1, 6*hidden, T)
+        return y[0].permute(0, 2, 1).reshape(-1, T).contiguous()         # (384, T)
+
+    def time_reach(self):
+        """Frames on either side that an output frame of `features` can depend on: every 3x3 conv reaches one row of its level
+        (2^level frames), a 2x2 average pool stays inside its cell, a k=3 s=2 transposed conv reaches one row of the coarser
+        level.  Rounded up to whole pooling cells plus one (cuts must sit on the coarsest pooling grid)."""
+        cell = 1 << len(self.enc)
+        r = 1                                                            # cnn
+        for lvl, blocks in enumerate(self.enc):
+            r += 2 * len(blocks) * (1 << lvl) + (1 << lvl)
+        r += 2 * len(self.inter) * cell
+        for i, (_, blocks) in enumerate(self.dec):
+            lvl = len(self.enc) - 1 - i
+            r += 2 * (1 << lvl) + 2 * len(blocks) * (1 << lvl)
+        return (r + cell - 1) // cell * cell + cell
+
+    def features_sharded(self, mel, group):
+        """`features` with the time axis cut over the ranks of `group` (the U-Net is the shardable part of the f0
+        branch; the recurrence behind it is not).  Every rank runs its segment plus `time_reach()` frames of real context on
+        either side -- inside that margin the segment's zero padding differs from the whole track's, beyond it nothing does --
+        keeps the interior and one all_gather of equal-size blocks rebuilds (384, T) everywhere.  Cuts sit on the coarsest
+        pooling grid.  Same arithmetic per output frame as the unsharded call; the conv dispatcher may pick other tiles for the
+        shorter problem, i.e. another fp32 summation order (~1e-7 relative, like any other tile change)."""
+        from . import dist as adist
+        rank, world = adist.world(group)
+        T = mel.shape[-1]
+        cell = 1 << len(self.enc)
+        halo = self.time_reach()
+        per = ((T + world - 1) // world + cell - 1) // cell * cell      # frames per rank, whole cells
+        if world == 1 or per < 2 * halo:                                 # short tracks: the margins would dominate
+            return self.features(mel)
+        a, b = min(rank * per, T), min((rank + 1) * per, T)
+        block = torch.zeros((mel.shape[1] * 3, per), dtype=torch.float32, device=mel.device)
+        if b > a:
+            lo, hi = max(0, a - halo), min(T, b + halo)
+            seg = self.features(mel[:, :, lo:hi].contiguous())
+            block[:, : b - a] = seg[:, a - lo: b - lo]
+        allb = adist.all_gather_equal(block.t().contiguous(), group)     # (world * per, 384): rank-major = time-major
+        return allb[:T].t().contiguous()
+
+    def __call__(self, mel, two_workgroups=None, group=None):
+        """mel (1, 128, T) with T % 32 == 0 -> salience (1, T, 360)."""
+        T = mel.shape[-1]
+        feat = (self.features(mel) if group is None else self.features_sharded(mel, group)).unsqueeze(0)   # (1, 384, T)
+        gi = ops.conv(feat, self.gru_in)                                 # (1, 6*hidden, T)
         hseq = ops.gru_bidir(gi[0], self.whh_t, self.bhh, self.hidden, two_workgroups)   # (2*hidden, T)
         sal = ops.conv(hseq.unsqueeze(0), self.fc, act=ops.ACT_SIGMOID)  # (1, 360, T)
         return sal[0].t().contiguous().unsqueeze(0)                      # (1, T, 360)
@@ -175,10 +218,10 @@ class RMVPE:
         cents_mapping = 20 * np.arange(360) + 1997.3794084376191
         self.cents_mapping = np.pad(cents_mapping, (4, 4))
 
-    def mel2hidden(self, mel, two_workgroups=None):
+    def mel2hidden(self, mel, two_workgroups=None, group=None):
         n_frames = mel.shape[-1]
         mel = F.pad(mel, (0, 32 * ((n_frames - 1) // 32 + 1) - n_frames), mode="reflect")  # frame re-indexing only
-        hidden = self.model(mel, two_workgroups)
+        hidden = self.model(mel, two_workgroups, group)
         return hidden[:, :n_frames]
 
     def _decode_device(self, hidden, thred):
@@ -194,20 +237,22 @@ class RMVPE:
         s = torch.as_tensor(salience).to(self.device)
         return self._decode_device(s, thred)[0].cpu().numpy()
 
-    def infer_from_audio_device(self, audio, thred=0.03, two_workgroups=None):
+    def infer_from_audio_device(self, audio, thred=0.03, two_workgroups=None, group=None):
         """infer_from_audio without the final device->host copy: everything is queued on the current stream.  The caller
-        must consult ops.gru_timed_out() once the stream has drained and, if set, call again with two_workgroups=False."""
+        must consult ops.gru_timed_out() once the stream has drained and, if set, call again with two_workgroups=False.
+        `group`: the ranks of a torch.distributed group split the U-Net over time (E2E.features_sharded); every rank must call."""
         if not torch.is_tensor(audio):
             audio = torch.from_numpy(np.asarray(audio))
         audio = audio.float().to(self.device).unsqueeze(0)
         mel = self.mel_extractor(audio, center=True)
-        hidden = self.mel2hidden(mel, two_workgroups)
+        hidden = self.mel2hidden(mel, two_workgroups, group)
         return self._decode_device(hidden[0], thred)[1]
 
-    def infer_from_audio(self, audio, thred=0.03):
-        f0 = self.infer_from_audio_device(audio, thred).cpu().numpy()
+    def infer_from_audio(self, audio, thred=0.03, group=None):
+        f0 = self.infer_from_audio_device(audio, thred, group=group).cpu().numpy()
         if ops.gru_timed_out():
             # the partner workgroups of the two-workgroup recurrence were not co-resident in time (busy / shared GPU):
-            # recompute on the single-workgroup kernel instead of failing the conversion
+            # recompute on the single-workgroup kernel instead of failing the conversion (locally, without the group: the
+            # other ranks may not have timed out and would not join a collective)
             f0 = self.infer_from_audio_device(audio, thred, two_workgroups=False).cpu().numpy()
         return f0

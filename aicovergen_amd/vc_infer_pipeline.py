@@ -117,6 +117,17 @@ class VC(object):
             return stack[0]
         return np.nanmedian(stack, axis=0)   # like the reference, estimators of different lengths raise here
 
+    def _rmvpe_group(self):
+        """Inside pipeline() the ranks of the job cut RMVPE's U-Net over time (rmvpe.E2E.features_sharded); a stand-alone
+        get_f0 call (no pipeline in progress) never communicates."""
+        import torch.distributed as td
+        if not getattr(self, "_in_pipeline", False) or not (td.is_available() and td.is_initialized()):
+            return None
+        g = getattr(self, "_group", None)
+        if (td.get_world_size(g) if g is not None else td.get_world_size()) < 2:
+            return None
+        return g if g is not None else td.group.WORLD
+
     def _rmvpe(self):
         if not hasattr(self, "model_rmvpe"):
             from .rmvpe import RMVPE
@@ -136,7 +147,7 @@ class VC(object):
         if _raw_f0 is not None:
             f0 = _raw_f0
         elif f0_method == "rmvpe":
-            f0 = self._rmvpe().infer_from_audio(x, thred=0.03)
+            f0 = self._rmvpe().infer_from_audio(x, thred=0.03, group=self._rmvpe_group())
         elif f0_method in ("mangio-crepe", "mangio-crepe-tiny"):
             f0 = self.get_f0_crepe_computation(host(x), f0_min, f0_max, p_len, crepe_hop_length,
                                                "tiny" if f0_method.endswith("tiny") else "full")
@@ -312,7 +323,8 @@ class VC(object):
             except Exception:
                 traceback.print_exc()
                 index = big_npy = None
-        self._group = group   # the crepe f0 methods shard their frames over it
+        self._group = group   # the crepe f0 methods shard their frames over it, RMVPE its U-Net
+        self._in_pipeline = True
         tp0 = ttime()
         audio, audio_pad, opt_ts, p_len = self.plan(audio)
         t1 = ttime()
@@ -363,7 +375,7 @@ class VC(object):
             side.wait_stream(main)
             tf0 = ttime()
             with torch.cuda.stream(side):
-                f0_dev = self._rmvpe().infer_from_audio_device(pad_dev, thred=0.03)
+                f0_dev = self._rmvpe().infer_from_audio_device(pad_dev, thred=0.03, group=self._rmvpe_group())
             for ci in mine:
                 s, e = bounds[ci]
                 feats_of[ci] = self._vc_features(model, pad_dev[s:e], index, big_npy, index_rate, version, use_protect)
@@ -432,6 +444,7 @@ class VC(object):
         # (overlapped schedule: f0_s = features of every chunk with the f0 branch underneath, f0_wait_s of it spent waiting for f0)
         self.last_profile = {"plan_s": t1 - tp0, "f0_s": t2 - t1, "chunks_s": tc1 - t2, "post_s": ttime() - tc1,
                              "f0_wait_s": f0_wait, "overlap_f0": float(bool(overlap))}
+        self._in_pipeline = False
         return audio_opt
 
 

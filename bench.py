@@ -262,7 +262,8 @@ def main():
                        "audio_seconds_total": seconds, "rvc_preset": "x_pad,x_query,x_center,x_max=3,10,60,65",
                        "stage_handover": "device (aicg_resample_poly); excluded like in the reference's metric: model load, WAV "
                                          "read/write, main.py mixing",
-                       "sharding": "mdx windows + rvc chunks over %d rank(s), all-gather join" % world,
+                       "sharding": "mdx windows + rvc chunks + rmvpe u-net time segments over %d rank(s), all-gather joins; the rmvpe bigru is "
+                                   "one recurrence over the track, computed on every rank" % world,
                        "stage_seconds_per_step": {"hubert": stage[0] / args.steps, "f0": stage[1] / args.steps,
                                                   "synth": stage[2] / args.steps},
                        "wall_split_seconds_per_step": split},
