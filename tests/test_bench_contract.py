@@ -1,0 +1,65 @@
+"""The bench line's contract (driver + judge read these keys), checked on the committed lines of this round and on bench.py's
+own helpers -- no GPU needed."""
+import glob
+import importlib.util
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOP = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+       "data", "config", "roofline"]
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_bench_*.json"))))
+def test_committed_bench_lines_follow_the_contract(path):
+    lines = [ln for ln in open(path).read().splitlines() if ln.strip()]
+    assert len(lines) == 1                                   # ONE JSON line on stdout
+    d = json.loads(lines[0])
+    for k in TOP:
+        assert k in d, k
+    assert d["metric"].startswith("real-time factor") and d["unit"] == "x real-time" and d["higher_is_better"] is True
+    assert d["n_gpus"] == 1 and d["vs_baseline"] is None and d["data"] == "synthetic" and d["scaling"] in ("weak", "strong")
+    assert abs(d["value"] - d["config"]["audio_seconds_total"] * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    split = d["dtype"].startswith("bf16x3")
+    assert split or d["dtype"] == "f32"
+    assert abs(r["peak"] - (2516.6 / 3 if split else 157.3)) < 0.1
+    assert (r["traffic"] is None) == split                   # the committed PMC passes are of the fp32 command
+    assert any(s["stage"].startswith("conv family") for s in d["stages"])
+    for s in d["stages"]:
+        assert s["bound"] in ("mfma", "hbm") and 0 < s["frac"] < 1
+    if "cpu_baseline" in d:
+        c = d["cpu_baseline"]
+        assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+
+
+def test_default_line_has_the_cpu_baseline():
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r02_bench_c3_default.json")).read())
+    assert d["config"]["config_id"] == "C3" and d["dtype"] == "f32" and "cpu_baseline" in d and d["roofline"]["traffic"] > 0
+
+
+def test_stage_table_and_traffic_helpers():
+    b = _bench()
+    conv = {"ms": 800.0, "tflops": 100.0}
+    stages = {"tdf_gemm_nt": {"ms": 100.0, "flops": 1e13, "bytes": 0.0}, "stft": {"ms": 4.0, "flops": 0.0, "bytes": 1.4e9},
+              "unused": {"ms": 0.0, "flops": 0.0, "bytes": 0.0}}
+    rows = b.stage_table(conv, stages, 2)
+    assert [r["stage"] for r in rows] == ["conv family (implicit GEMM)", "tdf_gemm_nt", "stft"]
+    assert rows[0]["ms_per_step"] == 400.0 and abs(rows[0]["frac"] - 100.0 / 157.3) < 1e-12
+    assert rows[1]["unit"] == "TFLOP/s" and abs(rows[1]["achieved"] - 100.0) < 1e-9
+    assert rows[2]["bound"] == "hbm" and abs(rows[2]["achieved"] - 350.0) < 1e-9
+    t = b.pmc_traffic_per_launch()
+    assert t is not None and t["fetch_x2"] > t["raw"] > 0 and t["source"].startswith("profiles/r02")
