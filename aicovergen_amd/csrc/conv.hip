@@ -233,11 +233,14 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
     // A launch should give each of the 256 CUs at least ~2 workgroups: shrink the tile for small problems
     // (HuBERT / enc_p GEMMs over a few thousand frames), M first (keeps the wide, coalesced N tile), then N.
     static const int ws = getenv("AICG_CONV_WS") ? atoi(getenv("AICG_CONV_WS")) : 1;
-    // 16-byte-fragment kernels (conv_ws3.h): every tile except the 160-row one, layers with >= 8 input channels per group
+    // 16-byte-fragment kernels (conv_ws3.h): layers with >= 8 input channels per group
     static const int v3 = getenv("AICG_CONV_V3") ? atoi(getenv("AICG_CONV_V3")) : 1;
     if (ws && v3 && p.w3 && p.Cin_g >= 8) {
         int rc = 1;
-        if (BM == 128 && blocks(128, 128) >= want) rc = run_ws3_128x128(p, st);
+        static const int v3_160 = getenv("AICG_CONV_V3_160") ? atoi(getenv("AICG_CONV_V3_160")) : 1;
+        // (the shuffle / multiplicative-skip instantiation of the 160-row tile spills inside its K loop: those layers stay classic)
+        if (BM == 160 && v3_160 && !p.shuffle && !p.res_mul && blocks(160, 128) >= want) rc = run_ws3_160x128(p, st);
+        else if (BM == 128 && blocks(128, 128) >= want) rc = run_ws3_128x128(p, st);
         else if (BM == 96 && blocks(96, 128) >= want) rc = run_ws3_96x128(p, st);
         else if (BM != 160 && M > 32 && blocks(64, 128) >= want) rc = run_ws3_64x128(p, st);
         if (rc == 1 && BM != 160) {

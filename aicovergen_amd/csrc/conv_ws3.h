@@ -18,8 +18,11 @@
 //   loads and writes one ds_write_b128.
 //
 // Everything else (producer / consumer roles, stage hand-over through one LDS-only barrier, buffer-resource loads with
-// range-checked zero padding, tile walk, epilogue) is conv_ws_kernel's.  Layers with fewer than 8 input channels per group and
-// the 160-row tile (5 x 16 accumulators + two sets of 16-byte fragments do not fit 128 registers) stay on conv_ws_kernel.
+// range-checked zero padding, tile walk, epilogue) is conv_ws_kernel's.  Layers with fewer than 8 input channels per group stay
+// on conv_ws_kernel.  The 160-row tile (5 x 16 accumulators: two sets of 16-byte fragments do not fit 128 registers) keeps ONE
+// set of A fragments and reloads each row's quad right behind the four MFMAs that consumed it (+3.5 ... 6 % over the
+// 4-byte-fragment kernel on the 144- / 160- / 480-channel layers); its shuffle / multiplicative-skip instantiation spills inside
+// the K loop, so those layers stay on conv_ws_kernel too.
 #pragma once
 #include "conv_kernels.h"
 
@@ -251,15 +254,48 @@ __global__ void __launch_bounds__(64 * (WM * WN + 4), (WM * WN == 4 ? 4 : 3)) co
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
                         }
             };
-            fetch(a0, b0, 0);
-            int s = 0;
-            for (; s + 2 <= ngroups; s += 2) {
-                fetch(a1, b1, s + 1);
-                mma(a0, b0);
-                fetch(a0, b0, s + 2);  // unconditional: past the last group this reads (never uses) the LDS slack rows
-                mma(a1, b1);
+            if constexpr (TM * TN <= 4) {
+                fetch(a0, b0, 0);
+                int s = 0;
+                for (; s + 2 <= ngroups; s += 2) {
+                    fetch(a1, b1, s + 1);
+                    mma(a0, b0);
+                    fetch(a0, b0, s + 2);  // unconditional: past the last group this reads (never uses) the LDS slack rows
+                    mma(a1, b1);
+                }
+                if (s < ngroups) mma(a0, b0);
+            } else {
+                // 5 accumulator tiles (the 160-row tile) leave room for ONE set of A fragments: each row's quad is reloaded for the
+                // next k-group right behind the four MFMAs that consumed it (256 cycles before its next use), the single B quad
+                // alternates between two sets requested a whole k-group ahead
+                static_assert(TN == 1, "rolling reload is written for one column tile per wave");
+                auto fetch_b = [&](float4& b) {
+                    b = xs[xoff + boff[0]];
+                    xoff += step_g;
+                    if (++gg == gpt) { gg = 0; xoff += next_tap; if (++kw == p.KW) { kw = 0; xoff += next_row; } }
+                };
+                auto step = [&](float4& b, float4& bn, int s) {
+                    const bool more = s + 1 < ngroups;
+                    if (more) fetch_b(bn);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i].x, b.x, acc[i][0], 0, 0, 0);
+                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i].y, b.y, acc[i][0], 0, 0, 0);
+                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i].z, b.z, acc[i][0], 0, 0, 0);
+                        acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[i].w, b.w, acc[i][0], 0, 0, 0);
+                        if (more) a0[i] = wt[(s + 1) * 2 * BM + i * 32];
+                    }
+                };
+                fetch_b(b0[0]);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a0[i] = wt[i * 32];
+                int s = 0;
+                for (; s + 2 <= ngroups; s += 2) {
+                    step(b0[0], b1[0], s);
+                    step(b1[0], b0[0], s + 1);
+                }
+                if (s < ngroups) step(b0[0], b1[0], s);
             }
-            if (s < ngroups) mma(a0, b0);
             tap0 += p.TT;
             if (tap0 >= p.taps) { tap0 = 0; ++c; }
         }
@@ -481,6 +517,7 @@ static int launch_conv_ws3m16(ConvArgs& p, hipStream_t stream) {
 // instantiation units (conv_ws3_*.hip)
 int run_ws3_128x128(ConvArgs& p, hipStream_t st);   // 4 consumers x (128 x 32), 32-row stages
 int run_ws3_96x128(ConvArgs& p, hipStream_t st);    // 4 consumers x (96 x 32)
+int run_ws3_160x128(ConvArgs& p, hipStream_t st);   // 4 consumers x (160 x 32), one A fragment set reloaded row by row
 int run_ws3_64x128(ConvArgs& p, hipStream_t st);    // 4 consumers (2 x 2) x (32 x 64)
 int run_ws3_64x64(ConvArgs& p, hipStream_t st);     // 4 consumers (2 x 2) x (32 x 32)
 int run_ws3_32x256(ConvArgs& p, hipStream_t st);    // 4 consumers x (32 x 64)

@@ -236,3 +236,26 @@ print("classic kernels ok")
     env = dict(os.environ, AICG_CONV_V3="0", AICG_CONV_V3M16="0")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "classic kernels ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_160_row_fragment_tile_in_a_subprocess():
+    """conv_ws3_kernel<160, 128, ...>: 5 accumulator tiles per wave, ONE set of A fragments reloaded row by row behind its MFMAs
+    (r2).  Driven on the emulator by lowering the fill target; 144 and 150 output channels (ragged last 32-row tile), taps split over
+    stages, channel tail, fused epilogue."""
+    code = r'''
+for (ci, co, k, d, T) in [(48, 144, 3, 1, 300), (40, 150, 7, 2, 260), (144, 144, 1, 1, 200)]:
+    x = torch.randn(2, ci, T)
+    w = torch.randn(co, ci, k) * 0.1
+    b, r = torch.randn(co), torch.randn(2, co, T)
+    pc = ops.PackedConv(w, b, padding=(k - 1) * d // 2, dilation=d)
+    y = ops.conv(x, pc, act=ops.ACT_RELU, res=r, pre_act=ops.ACT_LRELU, pre_slope=0.1)
+    e = rel(y, F.relu(F.conv1d(F.leaky_relu(x, 0.1), w, b, padding=(k - 1) * d // 2, dilation=d)) + r)
+    assert e < 1e-5, (ci, co, k, d, T, e)
+x = torch.randn(1, 144, 20, 70)
+w = torch.randn(144, 144, 3, 3) * 0.05
+pc = ops.PackedConv(w, None, padding=1)
+e = rel(ops.conv(x, pc), F.conv2d(x, w, None, padding=1))
+assert e < 1e-5, e
+print("160-row fragment tile ok")
+'''
+    _run_child(code, {"AICG_CONV_WANT": "1"}, "160-row fragment tile ok")
