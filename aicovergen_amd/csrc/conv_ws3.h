@@ -514,6 +514,149 @@ static int launch_conv_ws3m16(ConvArgs& p, hipStream_t stream) {
     return check_launch("conv_ws3m16_kernel");
 }
 
+// ---- 16x16x4 form on 8-byte fragments (48- / 16-row layers, r2) ------------------------------------------------------------------
+// The 8-row K groups and the (group, parity) planes of conv_ws3_kernel serve the 16x16x4 MFMA as well: lane (r16, q) takes plane
+// parity = q & 1 and of its quad the two elements 2 (q >> 1), 2 (q >> 1) + 1, i.e. rows 8 g + 4 (q >> 1) + 2 u + (q & 1) for
+// k-step u = 0, 1 -- four distinct rows per k-step, all eight covered: ONE ds_read_b64 per fragment per TWO k-steps, no larger
+// patch than conv_ws3_kernel's (the 16-byte form above needs 16-channel groups and lost to the 4-byte kernel for that reason).
+// Halves the LDS -> MFMA hand-overs of conv_ws16_kernel (one ~50-64-cycle bubble per 12 MFMAs of 32 cycles there).
+template <int BM, int XQ, int KS, bool GEN>
+__global__ void __launch_bounds__(512, 4) conv_ws3m16h_kernel(ConvArgs p) {
+    constexpr int CNT = 256;
+    constexpr int TM = BM / 16, TN = 4;
+    constexpr int WS_ELEMS = Ws3Geom<BM, KS>::WS_ELEMS;
+    constexpr int XS_ELEMS = XQ * 256 * 4;
+    HIP_DYNAMIC_SHARED(float, smem)
+    float* const xs0 = smem;
+    float* const ws0 = smem + 2 * XS_ELEMS;
+    const int tid = threadIdx.x;
+    const int bx = (int)xcd_remap(blockIdx.x, gridDim.x);
+    const int tw_i = bx % p.tiles_w;
+    const int th_i = (bx / p.tiles_w) % p.tiles_h;
+    const int n = bx / (p.tiles_w * p.tiles_h);
+    const int w0 = tw_i * p.TW, h0 = th_i * p.TH;
+    const int m_base = blockIdx.y * BM;
+    const int g = blockIdx.z;
+    const int stages_per_chunk = (p.taps + p.TT - 1) / p.TT;
+    const int nstages = p.nchunk * stages_per_chunk;
+    if (tid >= CNT) {
+        ws3_produce<BM, XQ, KS, false>(p, xs0, ws0, tid - CNT, n, g, h0, w0, m_base, nstages);
+        return;
+    }
+    const int lane = tid & 63, wn = tid >> 6;
+    const int q = lane >> 4, r16 = lane & 15;
+    const int par = q & 1, hq = q >> 1;
+    int boff[TN];   // float2 index inside a (group, parity) plane pair: 2 x (float4 index) + half
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int nl = wn * 64 + j * 16 + r16;
+        const int jh = nl >> p.TWlog2, jw = nl & (p.TW - 1);
+        boff[j] = 2 * (jh * p.sh * p.TWp + jw * p.sw + par * p.CHS) + hq;
+    }
+    f32x4 acc[TM][TN];
+    ws_init_acc16<TM, TN>(p, acc, g, m_base, q);
+    const int a_off = 2 * (par * BM + r16) + hq;   // float2 index inside a slab pair
+    {
+        int c = 0, tap0 = 0;
+        const int gpt = p.BKC >> 3;   // 8-row groups per tap
+        for (int st = 0; st < nstages; ++st) {
+            lds_barrier();  // stage st is in LDS
+            const float2* xs = reinterpret_cast<const float2*>(xs0 + (c & 1) * XS_ELEMS);
+            const float2* wt = reinterpret_cast<const float2*>(ws0 + (st & 1) * WS_ELEMS) + a_off;
+            const int nt = imin(p.TT, p.taps - tap0);
+            const int ngroups = nt * gpt;
+            const int kh0 = tap0 / p.KW;
+            int kw = tap0 - kh0 * p.KW, gg = 0;
+            int xoff = 2 * (kh0 * p.dh * p.TWp + kw * p.dw);   // float2 units
+            const int step_g = 4 * p.CHS, next_tap = 2 * p.dw - gpt * 4 * p.CHS, next_row = 2 * (p.dh * p.TWp - p.KW * p.dw);
+            float2 a0[TM], b0[TN], a1[TM], b1[TN];
+            auto fetch = [&](float2 (&a)[TM], float2 (&b)[TN], int s) {
+                const float2* xt = xs + xoff;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[i] = wt[s * 4 * BM + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = xt[boff[j]];
+                xoff += step_g;
+                if (++gg == gpt) { gg = 0; xoff += next_tap; if (++kw == p.KW) { kw = 0; xoff += next_row; } }
+            };
+            auto mma = [&](float2 (&a)[TM], float2 (&b)[TN]) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(u == 0 ? a[i].x : a[i].y, u == 0 ? b[j].x : b[j].y, acc[i][j], 0, 0, 0);
+            };
+            fetch(a0, b0, 0);
+            int s = 0;
+            for (; s + 2 <= ngroups; s += 2) {
+                fetch(a1, b1, s + 1);
+                mma(a0, b0);
+                fetch(a0, b0, s + 2);  // unconditional: past the last group this reads (never uses) the LDS slack rows
+                mma(a1, b1);
+            }
+            if (s < ngroups) mma(a0, b0);
+            tap0 += p.TT;
+            if (tap0 >= p.taps) { tap0 = 0; ++c; }
+        }
+    }
+    const bool interior = m_base + BM <= p.Cout_g && h0 + p.TH <= p.Ho && w0 + p.TW <= p.Wo;
+    if (!GEN && interior && p.wide_ok) {
+        lds_barrier();   // consumers only: every wave is done with the last stage, LDS is free
+        ws_epilogue16_wide<TM, TN>(p, acc, n, g, m_base, wn * 64, h0, w0, lane, smem + wn * kEpi16Scratch);
+    } else {
+        ws_epilogue16<TM, TN, GEN>(p, acc, n, g, m_base, wn * 64, h0, w0, r16, q, interior);
+    }
+}
+
+template <int BM>
+static int launch_conv_ws3m16h(ConvArgs& p, hipStream_t stream) {
+    constexpr int BN = 256, KS = KSTAGE;
+    if (p.Cin_g < 8 || !p.w3) return 1;
+    p.TW = choose_tile_width(p, BN);
+    p.TWlog2 = ilog2(p.TW);
+    p.TH = BN / p.TW;
+    p.TH_in = (p.TH - 1) * p.sh + (p.KH - 1) * p.dh + 1;
+    p.TW_in = (p.TW - 1) * p.sw + (p.KW - 1) * p.dw + 1;
+    p.TWp = p.TW_in | 1;
+    p.CHS = p.TH_in * p.TWp;
+    p.tiles_w = idiv_up(p.Wo, p.TW);
+    p.tiles_h = idiv_up(p.Ho, p.TH);
+    p.BKC = 32;
+    while (p.BKC > 8 && (p.BKC * p.CHS > 12 * 256 || p.BKC >= 2 * p.Cin_g)) p.BKC >>= 1;
+    p.BKClog2 = ilog2(p.BKC);
+    {
+        const int cap = imax(1, KS / p.BKC);
+        const int nstg = idiv_up(p.taps, cap);
+        p.TT = idiv_up(p.taps, nstg);
+    }
+    p.nchunk = idiv_up(p.Cin_g, p.BKC);
+    p.xs_total = p.BKC * p.CHS;
+    p.xs_elems = (p.xs_total + 3) & ~3;
+    p.div_chs = div_mul(p.CHS);
+    p.div_twp = div_mul(p.TWp);
+    if (p.xs_total > 12 * 256) return 1;
+    const int xq = idiv_up(p.xs_total / 4, 256) <= 2 ? 2 : 3;
+    const size_t lds = (size_t)(2 * xq * 256 * 4 + 2 * Ws3Geom<BM, KS>::WS_ELEMS) * sizeof(float);
+    const bool off_ok = (long)(p.BKC + 8) * p.x_sc + (long)p.H * p.x_sh < (1L << 29) && (long)p.taps * p.Cin_pad * p.Mpad < (1L << 29);
+    if (lds > 160 * 1024 || !off_ok || (long)p.xs_total * p.CHS >= (1L << 32)) return 1;
+    const long gx = (long)p.N * p.tiles_h * p.tiles_w;
+    if (gx > 2147483647L) return fail(AICG_E_SHAPE, "conv: too many output tiles");
+    dim3 grid((unsigned)gx, (unsigned)idiv_up(p.Cout_g, BM), (unsigned)p.groups);
+    const bool gen = p.shuffle || p.res_mul;
+    p.stagger = p.stagger_first = 0;
+    {
+        static const int wide = getenv("AICG_CONV_WIDE") ? atoi(getenv("AICG_CONV_WIDE")) : 1;
+        p.wide_ok = wide && (size_t)4 * kEpi16Scratch * sizeof(float) <= lds ? conv_wide_ok(p) : 0;
+    }
+    auto kern = gen ? (xq == 2 ? conv_ws3m16h_kernel<BM, 2, KS, true> : conv_ws3m16h_kernel<BM, 3, KS, true>)
+                    : (xq == 2 ? conv_ws3m16h_kernel<BM, 2, KS, false> : conv_ws3m16h_kernel<BM, 3, KS, false>);
+    allow_dynamic_lds((const void*)kern, lds);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, stream, p);
+    return check_launch("conv_ws3m16h_kernel");
+}
+
 // instantiation units (conv_ws3_*.hip)
 int run_ws3_128x128(ConvArgs& p, hipStream_t st);   // 4 consumers x (128 x 32), 32-row stages
 int run_ws3_96x128(ConvArgs& p, hipStream_t st);    // 4 consumers x (96 x 32)
@@ -524,5 +667,7 @@ int run_ws3_32x256(ConvArgs& p, hipStream_t st);    // 4 consumers x (32 x 64)
 int run_ws3_32x128(ConvArgs& p, hipStream_t st);    // 4 consumers x (32 x 32)
 int run_ws3m16_48(ConvArgs& p, hipStream_t st);     // 16x16x4 tiles, 48 rows x 256 positions
 int run_ws3m16_16(ConvArgs& p, hipStream_t st);     //                16 rows x 256 positions
+int run_ws3m16h_48(ConvArgs& p, hipStream_t st);    // 16x16x4 tiles on 8-byte fragments, 48 rows x 256 positions
+int run_ws3m16h_16(ConvArgs& p, hipStream_t st);    //                                     16 rows x 256 positions
 
 }  // namespace aicg

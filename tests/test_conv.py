@@ -207,7 +207,7 @@ for (ci, co, h, w, k) in [(16, 16, 1, 70000, 3), (32, 48, 6, 11000, 1), (40, 40,
     assert e < 1e-5, (ci, co, h, w, k, e)
 print("m16 fragment kernels ok")
 '''
-    _run_child(code, {"AICG_CONV_V3M16": "1"}, "m16 fragment kernels ok")
+    _run_child(code, {"AICG_CONV_V3M16": "1", "AICG_CONV_M16H": "0"}, "m16 fragment kernels ok")
 
 
 def test_classic_wave_specialised_kernels_in_a_subprocess():
@@ -233,7 +233,7 @@ for (n, ci, co, h, w, k) in [(1, 24, 96, 12, 200, 3), (1, 16, 16, 1, 70000, 3), 
     assert e < 1e-5, (n, ci, co, h, w, k, e)
 print("classic kernels ok")
 ''' % (root, os.path.join(root, "tests"))
-    env = dict(os.environ, AICG_CONV_V3="0", AICG_CONV_V3M16="0")
+    env = dict(os.environ, AICG_CONV_V3="0", AICG_CONV_V3M16="0", AICG_CONV_M16H="0")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "classic kernels ok" in out.stdout, out.stdout + out.stderr
 
@@ -259,3 +259,21 @@ assert e < 1e-5, e
 print("160-row fragment tile ok")
 '''
     _run_child(code, {"AICG_CONV_WANT": "1"}, "160-row fragment tile ok")
+
+
+def test_16x16x4_on_8_byte_fragments_in_a_subprocess():
+    """conv_ws3m16h_kernel (r2 default for 48- / 16-row layers with >= 8 input channels and >= 65 536 positions: MDX-Net / RMVPE level
+    0): lane (r16, q) reads half a quad of plane q & 1; channel tail (40 of 48), ragged last tile, 1-D and 2-D, fused epilogue."""
+    code = r'''
+for (ci, co, h, w, k) in [(16, 16, 1, 70000, 3), (32, 48, 6, 11000, 1), (40, 40, 3, 22000, 3), (8, 48, 2, 33000, 3)]:
+    x = torch.randn(1, ci, h, w)
+    wt = torch.randn(co, ci, k if h > 1 else 1, k) * 0.1
+    b, r = torch.randn(co), torch.randn(1, co, h, w)
+    pad = (k // 2 if h > 1 else 0, k // 2)
+    pc = ops.PackedConv(wt, b, padding=pad)
+    y = ops.conv(x, pc, act=ops.ACT_RELU, res=r)
+    e = rel(y, F.relu(F.conv2d(x, wt, b, padding=pad)) + r)
+    assert e < 1e-5, (ci, co, h, w, k, e)
+print("m16 half-quad kernels ok")
+'''
+    _run_child(code, {"AICG_CONV_M16H": "1"}, "m16 half-quad kernels ok")
