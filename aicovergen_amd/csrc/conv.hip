@@ -226,7 +226,7 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
     }
     // 8-byte fragments (conv_ws3m16h_kernel): the same 8-row K groups as the 32 x 32 kernels, half the hand-overs of conv_ws16_kernel
     static const int m16h = getenv("AICG_CONV_M16H") ? atoi(getenv("AICG_CONV_M16H")) : 1;
-    if (use16 && m16h && p.w3 && p.Cin_g >= 8 && npos >= 256L * 256) {
+    if (use16 && m16h && !d->frozen_narrow && p.w3 && p.Cin_g >= 8 && npos >= 256L * 256) {
         int rc = 1;
         if (M > 32 && M <= 48) rc = run_ws3m16h_48(p, st);
         else if (M <= 16) rc = run_ws3m16h_16(p, st);

@@ -146,7 +146,7 @@ class ConvDesc(ctypes.Structure):
                 ("act_slope", ctypes.c_float), ("out_scale", ctypes.c_float), ("accumulate", ctypes.c_int32),
                 ("res_before_act", ctypes.c_int32), ("pad_h_end", ctypes.c_int32), ("pad_w_end", ctypes.c_int32),
                 ("shuffle", ctypes.c_int32), ("res_mul", ctypes.c_int32), ("packed_v3", ctypes.c_int32),
-                ("split", ctypes.c_int32)]
+                ("split", ctypes.c_int32), ("frozen_narrow", ctypes.c_int32)]
 
 
 def conv_bkc(taps):
@@ -158,16 +158,21 @@ def conv_bkc(taps):
 split_precision = os.environ.get("AICG_PRECISION", "fp32").lower() in ("bf16x3", "split")
 
 
+_fp32_depth = 0
+
+
 @contextlib.contextmanager
 def fp32_layers():
     """Layers packed inside this block stay on the fp32 MFMA whatever AICG_PRECISION says: the f0 estimators and the retrieval
     search select INDICES (pitch bins, neighbour ids), which are kept bit-exact (BASELINE north_star)."""
-    global split_precision
+    global split_precision, _fp32_depth
     old, split_precision = split_precision, False
+    _fp32_depth += 1
     try:
         yield
     finally:
         split_precision = old
+        _fp32_depth -= 1
 
 
 def fp32_only(fn):
@@ -229,6 +234,7 @@ class PackedConv:
         self.stride, self.padding, self.dilation = stride, padding, dilation
         device = weight.device if device is None else device
         self.split = bool(split_precision)
+        self.frozen_narrow = bool(_fp32_depth)   # packed inside fp32_layers(): an f0 model (aicg_conv_desc.frozen_narrow)
         self.w = pack_conv_weight(weight.to(device), groups, self.split)
         self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
 
@@ -319,6 +325,7 @@ def conv(x, pc, res=None, out=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NON
     d.shuffle, d.res_mul = int(shuffle), 1 if res_mul else 0
     d.packed_v3 = 1
     d.split = 1 if getattr(pc, "split", False) else 0
+    d.frozen_narrow = 1 if getattr(pc, "frozen_narrow", False) else 0
     prof = conv_profile
     if prof is not None and x.is_cuda:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

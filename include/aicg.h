@@ -119,6 +119,11 @@ typedef struct aicg_conv_desc {
                                      group and more than 16 output channels are then computed as hi*hi + hi*lo + lo*hi on the
                                      bf16 matrix pipe with fp32 accumulation (csrc/conv_ws3s.h: ~1e-5 relative to the fp32
                                      kernels); the other layers run the fp32 kernels unchanged */
+    int32_t frozen_narrow;        /* nonzero: 16- / 48-row layers of this model keep the round-1 4-byte-fragment kernel instead of the
+                                     8-byte-fragment one.  Set for the f0 estimators: both kernels are equally close to the fp32
+                                     reference (~3e-7), but f0 feeds the vocoder's phase accumulator, where ANY change of summation
+                                     order moves the end-to-end waveform at the 1e-4 level -- their numerics stay as the goldens
+                                     were validated */
 } aicg_conv_desc;
 
 int aicg_conv_bkc(int taps);

@@ -81,6 +81,15 @@ def test_split_is_not_plain_bf16(dev, split):
     assert rel_rms(y, ref) < TOL
 
 
+def test_f0_models_freeze_their_narrow_kernels():
+    """Layers packed inside ops.fp32_layers() (RMVPE, CREPE, retrieval) carry aicg_conv_desc.frozen_narrow."""
+    w = torch.randn(16, 16, 3)
+    assert not ops.PackedConv(w, None).frozen_narrow
+    with ops.fp32_layers():
+        assert ops.PackedConv(w, None).frozen_narrow
+    assert not ops.PackedConv(w, None).frozen_narrow
+
+
 def test_default_is_fp32():
     import os
     if os.environ.get("AICG_PRECISION", "fp32").lower() == "fp32":
