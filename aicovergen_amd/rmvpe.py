@@ -187,7 +187,7 @@ class E2E:
         if world == 1 or per < 2 * halo:                                 # short tracks: the margins would dominate
             return self.features(mel)
         a, b = min(rank * per, T), min((rank + 1) * per, T)
-        block = torch.zeros((mel.shape[1] * 3, per), dtype=torch.float32, device=mel.device)
+        block = torch.zeros((mel.shape[1] * self.cnn.cout, per), dtype=torch.float32, device=mel.device)
         if b > a:
             lo, hi = max(0, a - halo), min(T, b + halo)
             seg = self.features(mel[:, :, lo:hi].contiguous())
