@@ -52,14 +52,15 @@ def test_two_rank_sharding_matches_single_process():
     model = MDXModel("cpu", cfg["dim_f"], cfg["dim_t"], cfg["n_fft"], hop=64)
     sess = MDX(None, model, state_dict=weights.mdx_state_dict(cfg, 1234))
     wave = song_like(0.2, 44100, seed=3)[:, :7000]
-    ref_sep = run_mdx_arrays(sess, wave, True, 2)
-    ref_out, _, _ = tp.run(conftest.Dev("emu"), weights.small_model_set(1234), vocal_like(2.6, 16000, 1239))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 500)
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
+    # the single-process result is computed while the ranks run (they take two emulator threads each)
+    ref_sep = run_mdx_arrays(sess, wave, True, 2)
+    ref_out, _, _ = tp.run(conftest.Dev("emu"), weights.small_model_set(1234), vocal_like(2.6, 16000, 1239))
     sep, out = q.get(timeout=500)
     for p in procs:
         p.join(60)
@@ -120,14 +121,14 @@ def _three_rank_case(group):
 def test_three_rank_uneven_sharding_matches_single_process():
     import conftest
     conftest._bind("emu")
-    ref_sep, ref_outs, n_windows, n_chunks = _three_rank_case(None)
-    assert n_windows % 3 != 0 and n_chunks == 2          # an uneven window split and fewer chunks than ranks
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 30100 + (os.getpid() % 500)
     procs = [ctx.Process(target=_worker3, args=(r, 3, port, q)) for r in range(3)]
     for p in procs:
         p.start()
+    ref_sep, ref_outs, n_windows, n_chunks = _three_rank_case(None)   # while the ranks run
+    assert n_windows % 3 != 0 and n_chunks == 2          # an uneven window split and fewer chunks than ranks
     sep, outs, _, _ = q.get(timeout=800)
     for p in procs:
         p.join(60)
@@ -206,14 +207,14 @@ def test_rmvpe_unet_time_shard_matches_unsharded():
     whole (bit-identical)."""
     import conftest
     conftest._bind("emu")
-    ref_feat, ref_sal, ref_short, reach, ref_f0 = _rmvpe_case(False)
-    assert reach == 320 and 672 >= 2 * reach
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 30700 + (os.getpid() % 500)
     procs = [ctx.Process(target=_worker_rmvpe, args=(r, 3, port, q)) for r in range(3)]
     for p in procs:
         p.start()
+    ref_feat, ref_sal, ref_short, reach, ref_f0 = _rmvpe_case(False)   # while the ranks run
+    assert reach == 320 and 672 >= 2 * reach
     got = [q.get(timeout=800) for _ in range(3)]
     for p in procs:
         p.join(60)
