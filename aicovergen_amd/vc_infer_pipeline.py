@@ -7,6 +7,7 @@ truncating int16 conversion, the in-place `times = [hubert, f0, synth]` accounti
 Moved to the device: HuBERT, RMVPE (incl. the salience decode and the coarse-pitch quantiser), the feature
 upsample / protect blend and the whole synthesizer.  Host numpy keeps the O(N) pre/post steps.
 """
+import functools
 import os
 import traceback
 from time import time as ttime
@@ -47,6 +48,19 @@ def change_rms(data1, sr1, data2, sr2, rate):
     rms2 = torch.max(rms2, torch.zeros_like(rms2) + 1e-6)
     data2 *= (torch.pow(rms1, torch.tensor(1 - rate)) * torch.pow(rms2, torch.tensor(rate - 1))).numpy()
     return data2
+
+
+def _bracket_pipeline(fn):
+    """While VC.pipeline runs, the f0 estimators may use the job's process group (VC._rmvpe_group) -- and never outside it,
+    whatever happens inside the call."""
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        self._in_pipeline = True
+        try:
+            return fn(self, *args, **kwargs)
+        finally:
+            self._in_pipeline = False
+    return wrapper
 
 
 class VC(object):
@@ -295,6 +309,7 @@ class VC(object):
         bounds.append((t if t is not None else 0, audio_pad.shape[0]))
         return bounds
 
+    @_bracket_pipeline
     def pipeline(self, model, net_g, sid, audio, input_audio_path, times, f0_up_key, f0_method, file_index, index_rate,
                  if_f0, filter_radius, tgt_sr, resample_sr, rms_mix_rate, version, protect, crepe_hop_length, f0_file=None,
                  noise_fn=None, group=None, noise_seed=None):
@@ -324,7 +339,6 @@ class VC(object):
                 traceback.print_exc()
                 index = big_npy = None
         self._group = group   # the crepe f0 methods shard their frames over it, RMVPE its U-Net
-        self._in_pipeline = True
         tp0 = ttime()
         audio, audio_pad, opt_ts, p_len = self.plan(audio)
         t1 = ttime()
@@ -444,7 +458,6 @@ class VC(object):
         # (overlapped schedule: f0_s = features of every chunk with the f0 branch underneath, f0_wait_s of it spent waiting for f0)
         self.last_profile = {"plan_s": t1 - tp0, "f0_s": t2 - t1, "chunks_s": tc1 - t2, "post_s": ttime() - tc1,
                              "f0_wait_s": f0_wait, "overlap_f0": float(bool(overlap))}
-        self._in_pipeline = False
         return audio_opt
 
 
