@@ -40,7 +40,9 @@ MFMA_PEAK = PEAK_F32_MFMA  # of the arithmetic in use: --precision bf16x3 spends
 PEAK_HBM = 8000.0       # GB/s spec (6290 measured float4 copy)
 
 
-def build_models(device, config, n_mdx):
+def build_models(device, config, n_mdx, tiny=False, preset="fp16"):
+    """`tiny` (tests/test_bench_launch.py only, never on a GPU box): the miniature networks of the CPU suite, so that the launch /
+    sharding / reporting logic of this file can be exercised end to end on the kernel emulator."""
     from aicovergen_amd.hubert import HubertModel
     from aicovergen_amd.infer_pack.models import SynthesizerTrnMs768NSFsid
     from aicovergen_amd.mdx import MDX, MDXModel
@@ -49,12 +51,26 @@ def build_models(device, config, n_mdx):
     from aicovergen_amd.vc_infer_pipeline import VC
     from synthetic import weights
     mdxs = []
-    for i, mcfg in enumerate([weights.MDX_VOC_FT, weights.MDX_KARA2, weights.MDX_REVERB_HQ][:n_mdx]):
-        model = MDXModel(device, mcfg["dim_f"], mcfg["dim_t"], mcfg["n_fft"], stem_name="Vocals", compensation=1.021)
+    for i, mcfg in enumerate([weights.MDX_TINY] if tiny else [weights.MDX_VOC_FT, weights.MDX_KARA2, weights.MDX_REVERB_HQ][:n_mdx]):
+        model = MDXModel(device, mcfg["dim_f"], mcfg["dim_t"], mcfg["n_fft"], hop=64 if tiny else 1024, stem_name="Vocals",
+                         compensation=1.021)
         mdxs.append(MDX(None, model, state_dict=weights.mdx_state_dict(mcfg, 1234 + i)))
     if config == "C2":
         return mdxs, None, None, None
-    cfg = Config(str(device), True)  # what main.py selects: the "6G" fp16 preset x = (3, 10, 60, 65)
+    if tiny:
+        nets = weights.small_model_set(1234)
+        cfg = type("TinyCfg", (), dict(x_pad=1, x_query=1, x_center=1, x_max=2, is_half=False, device=device))()
+        vc = VC(nets["synth_cfg"][-1], cfg)
+        hub = HubertModel(nets["hubert_sd"], nets["hubert_cfg"]).to(device)
+        vc.model_rmvpe = RMVPE(None, False, device, state_dict=nets["rmvpe_sd"])
+        net_g = SynthesizerTrnMs768NSFsid(*nets["synth_cfg"], is_half=False)
+        del net_g.enc_q
+        net_g.load_state_dict(nets["synth_sd"], strict=False)
+        net_g.eval().to(device)
+        return mdxs, vc, hub, net_g
+    # Config's is_half only selects the chunk geometry here (all kernels compute in fp32): True = what main.py:196 passes, the
+    # "fp16" preset x_pad, x_query, x_center, x_max = 3, 10, 60, 65; False = the fp32 preset 1, 6, 38, 41 (src/rvc.py:76-93)
+    cfg = Config(str(device), preset == "fp16")
     cfg.device = device
     vc = VC(40000, cfg)
     hub = HubertModel(weights.hubert_state_dict(weights.HUBERT_BASE, 1234), weights.HUBERT_BASE).to(device)
@@ -70,7 +86,7 @@ def build_models(device, config, n_mdx):
     return mdxs, vc, hub, net_g
 
 
-def one_step(config, mdxs, vc, hub, net_g, wave44_dev, group):
+def one_step(config, mdxs, vc, hub, net_g, wave44_dev, group, emu=False):
     from aicovergen_amd import dist as adist
     from aicovergen_amd import ops
     t0 = time.perf_counter()
@@ -79,17 +95,19 @@ def one_step(config, mdxs, vc, hub, net_g, wave44_dev, group):
         if i > 0:
             sep = sep / ops.absmax(sep.reshape(-1)).clamp_min(1e-12)   # (mdx.py:258-259)
         sep = adist.mdx_separate(m, sep, True, 2, group)
-    torch.cuda.synchronize()  # stage boundary (the reference writes the stems to disk here)
+    if not emu:
+        torch.cuda.synchronize()  # stage boundary (the reference writes the stems to disk here)
     mdx_s = time.perf_counter() - t0
     if config == "C2":
         return sep, None, [0, 0, 0], {"mdx_s": mdx_s}
     t1 = time.perf_counter()
     wave16 = ops.resample_poly_mono(sep, 44100, 16000)      # stereo 44.1 kHz -> mono 16 kHz, stays in HBM
-    torch.cuda.synchronize()
+    if not emu:
+        torch.cuda.synchronize()
     times = [0, 0, 0]
     method = "mangio-crepe" if config == "C4" else "rmvpe"
-    out = vc.pipeline(hub, net_g, 0, wave16, "synthetic.wav", times, 0, method, "", 0.5, 1, 3, 40000, 0, 0.25, "v2", 0.33, 128,
-                      group=group, noise_seed=1234)
+    out = vc.pipeline(hub, net_g, 0, wave16, "synthetic.wav", times, 0, method, "", 0.5, 1, 3, vc.t_pad_tgt // vc.x_pad, 0, 0.25,
+                      "v2", 0.33, 128, group=group, noise_seed=1234)
     return sep, out, times, dict(vc.last_profile, mdx_s=mdx_s, resample_s=time.perf_counter() - t1 - sum(
         vc.last_profile[k] for k in ("plan_s", "f0_s", "chunks_s", "post_s")))
 
@@ -162,6 +180,43 @@ def stage_table(conv, stages, steps):
     return rows
 
 
+def reference_cpu_record():
+    """The reference's OWN VC.pipeline (its unmodified code, CPU fp32) on BASELINE C1's 30 s input, as timed by
+    tests/golden/make_golden.py when it produced the committed golden -- in the BUILD container (8 vCPU), not on this box:
+    /root/reference does not travel.  Reported next to the live port timing, never mixed into it."""
+    try:
+        g = np.load(os.path.join(ROOT, "tests", "golden", "pipeline_c1_30s.npz"))
+        sec, thr, dur = float(g["ref_cpu_seconds"][0]), int(g["ref_threads"][0]), float(g["seconds"][0])
+        return {"ref_cpu_seconds": sec, "ref_audio_seconds": dur, "ref_threads": thr, "ref_rtf_rvc_only": dur / sec,
+                "ref_where": "reference src/vc_infer_pipeline.py VC.pipeline (rmvpe, fp32, C1 30 s) in the build container; "
+                             "recorded in tests/golden/pipeline_c1_30s.npz"}
+    except Exception:
+        return {}
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks ourselves, exactly the way the
+    driver does (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`), one rank per GPU
+    over RCCL, and pass rank 0's single JSON line through.  Returns the exit code, or None when this process is a rank itself
+    (RANK / WORLD_SIZE present) or N == 1."""
+    if args.gpus <= 1 or "RANK" in os.environ or "WORLD_SIZE" in os.environ:
+        return None
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL's only working mode on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,7 +224,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", choices=["C2", "C3", "C4", "C5"], default="C3")
     ap.add_argument("--mdx-models", type=int, default=1, choices=[1, 3])
+    ap.add_argument("--preset", choices=["fp16", "fp32"], default="fp16",
+                    help="RVC chunk geometry (src/rvc.py:76-93): fp16 = x_pad,x_query,x_center,x_max 3,10,60,65 (what main.py "
+                         "selects, the headline), fp32 = 1,6,38,41.  Geometry only: the arithmetic is fp32 either way")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile-step", action="store_true", help="skip the extra instrumented step behind the timed region")
     ap.add_argument("--precision", choices=["fp32", "bf16x3"], default=None,
                     help="arithmetic of the conv / TDF GEMM family: fp32 MFMA (default, the headline) or the opt-in split precision "
                          "(bf16 hi + lo operands, 3 bf16 MFMAs per product, fp32 accumulation); default: $AICG_PRECISION or fp32")
@@ -177,19 +236,42 @@ def main():
     ap.add_argument("--dump", type=str, default=None, help="write the last step's outputs (npz) for cross-checking runs")
     args = ap.parse_args()
 
+    rc = self_launch(args)
+    if rc is not None:
+        sys.exit(rc)
+
+    # stdout carries exactly ONE line (rank 0's JSON): everything else this process or its native libraries (gloo / RCCL banners,
+    # the synthesizer constructors' prints) write to file descriptor 1 goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch.distributed as td
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    if os.environ.get("AICG_FORCE_DEVICE") is not None:   # debugging aid: several ranks on one GPU (with gloo)
-        local = int(os.environ["AICG_FORCE_DEVICE"])
-    torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE); refusing to report a line for a "
+                 "different job size" % (args.gpus, world))
+    # TEST HOOK (tests/test_bench_launch.py): the kernel emulator on host tensors with the miniature networks -- exercises
+    # the launch, sharding and reporting logic of this file without a GPU.  Never set on a GPU box; the line says so.
+    emu = os.environ.get("AICG_BENCH_EMU") == "1"
+    if emu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import conftest
+        conftest._bind("emu")
+        device = torch.device("cpu")
+    else:
+        if os.environ.get("AICG_FORCE_DEVICE") is not None:   # debugging aid: several ranks on one GPU (with gloo)
+            local = int(os.environ["AICG_FORCE_DEVICE"])
+        if local >= torch.cuda.device_count():
+            sys.exit("bench.py: rank %d needs cuda:%d but only %d device(s) are visible" % (rank, local, torch.cuda.device_count()))
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
     group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("AICG_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
+        backend = os.environ.get("AICG_DIST_BACKEND", "gloo" if emu else "nccl")   # "nccl" is RCCL on ROCm
         if backend == "nccl":
             td.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
         else:
@@ -208,42 +290,59 @@ def main():
     else:
         seconds = (args.track_seconds or TRACK_S) * world   # weak scaling: 240 s per GPU
     with contextlib.redirect_stdout(sys.stderr):      # the synthesizer constructors print like the reference's do
-        mdxs, vc, hub, net_g = build_models(device, args.config, args.mdx_models)
+        mdxs, vc, hub, net_g = build_models(device, args.config, args.mdx_models, tiny=emu, preset=args.preset)
     wave44 = song_like(seconds, 44100, 1234)
     wave44 = wave44 / max(np.max(wave44), abs(np.min(wave44)))
     wave44_dev = torch.from_numpy(wave44).to(device)     # inputs resident in HBM before the timed region
 
+    def sync():
+        if not emu:
+            torch.cuda.synchronize()
+
     def barrier():
         if world > 1:
             td.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     with contextlib.redirect_stdout(sys.stderr):
         for _ in range(args.warmup):
-            one_step(args.config, mdxs, vc, hub, net_g, wave44_dev, group)
-        prof = sprof = None
-        if rank == 0:
-            prof, sprof = ops.ConvProfile(), ops.StageProfile()
-            ops.conv_profile, ops.stage_profile = prof, sprof
+            one_step(args.config, mdxs, vc, hub, net_g, wave44_dev, group, emu)
+        # ---- the timed region: K steps, no instrumentation (no HIP events, no per-launch accounting) ----
         barrier()
         t0 = time.perf_counter()
         stage = [0.0, 0.0, 0.0]
         split = {}
         for _ in range(args.steps):
-            sep, out, times, prof_s = one_step(args.config, mdxs, vc, hub, net_g, wave44_dev, group)
+            sep, out, times, prof_s = one_step(args.config, mdxs, vc, hub, net_g, wave44_dev, group, emu)
             stage = [a + b for a, b in zip(stage, times)]
             for k, v in prof_s.items():
                 split[k] = split.get(k, 0.0) + v / args.steps
         barrier()
         dt = time.perf_counter() - t0
-    ops.conv_profile = ops.stage_profile = None
-    tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        # ---- one more step of the same work with a HIP event pair around every conv / staged launch (roofline + stage table):
+        # ~2 700 event records per step, kept OUT of the timed region; its own wall time is reported as profiled_step_ms ----
+        prof = sprof = None
+        prof_ms = None
+        if not args.no_profile_step and not emu:
+            if rank == 0:
+                prof, sprof = ops.ConvProfile(), ops.StageProfile()
+                ops.conv_profile, ops.stage_profile = prof, sprof
+            barrier()
+            tp = time.perf_counter()
+            one_step(args.config, mdxs, vc, hub, net_g, wave44_dev, group, emu)
+            barrier()
+            prof_ms = (time.perf_counter() - tp) * 1e3
+            ops.conv_profile = ops.stage_profile = None
+    dts = torch.tensor([dt], dtype=torch.float64, device=device)
+    per_rank = [dt]
     if world > 1:
-        td.all_reduce(tmax, op=td.ReduceOp.MAX)
-    dt = float(tmax.item())
+        allt = [torch.empty_like(dts) for _ in range(world)]
+        td.all_gather(allt, dts)
+        per_rank = [float(t.item()) for t in allt]
+    dt = max(per_rank)                                   # MAX over ranks
     if rank == 0:
         ms = dt / args.steps * 1e3
-        conv = prof.summary()
+        x = (vc.x_pad, vc.x_query, vc.x_center, vc.x_max) if vc is not None else None
         workload = {
             "C2": "C2: %d s 44.1 kHz stereo -> MDX-Net (%d model(s), Voc_FT-class 3072/256/7680, denoise) only",
             "C3": "C3: %d s 44.1 kHz stereo -> MDX-Net (%d model(s), Voc_FT-class 3072/256/7680, denoise) -> vocals resampled on the "
@@ -251,7 +350,8 @@ def main():
             "C4": "C4: %d s 44.1 kHz stereo -> MDX-Net (%d model(s)) -> device resample -> RVC with mangio-crepe f0 (CREPE-full, hop 128)",
             "C5": "C5: one %d s 44.1 kHz stereo track -> MDX-Net (%d model(s)) -> device resample -> RVC (rmvpe), sharded over the ranks",
         }[args.config] % (int(seconds), args.mdx_models) + ", seeded random weights"
-        traffic = None if split_mode else pmc_traffic_per_launch()   # the committed PMC passes are of the default (fp32) command
+        if emu:
+            workload = "TEST HOOK (kernel emulator, miniature networks, host tensors) -- not a measurement: " + workload
         res = {
             "metric": "real-time factor (audio-sec/wall-sec) for MDX+RVC on 4-min 44.1 kHz track",
             "value": seconds * args.steps / dt, "unit": "x real-time", "n_gpus": world, "steps": args.steps,
@@ -259,35 +359,47 @@ def main():
             "vs_baseline": None, "dtype": "bf16x3 (bf16 hi+lo operands, f32 accumulate; f0 / kNN f32)" if split_mode else "f32",
             "data": "synthetic",
             "config": {"workload": workload, "config_id": args.config, "mdx_models": args.mdx_models,
-                       "audio_seconds_total": seconds, "rvc_preset": "x_pad,x_query,x_center,x_max=3,10,60,65",
+                       "audio_seconds_total": seconds,
+                       "rvc_preset": None if x is None else "x_pad,x_query,x_center,x_max=%d,%d,%d,%d" % x,
                        "stage_handover": "device (aicg_resample_poly); excluded like in the reference's metric: model load, WAV "
                                          "read/write, main.py mixing",
                        "sharding": "mdx windows + rvc chunks + rmvpe u-net time segments over %d rank(s), all-gather joins; the rmvpe bigru is "
                                    "one recurrence over the track, computed on every rank" % world,
+                       "per_rank_seconds_per_step": [t / args.steps for t in per_rank],
                        "stage_seconds_per_step": {"hubert": stage[0] / args.steps, "f0": stage[1] / args.steps,
                                                   "synth": stage[2] / args.steps},
-                       "wall_split_seconds_per_step": split},
-            "roofline": {"bound": "mfma", "achieved": conv["tflops"], "peak": MFMA_PEAK, "unit": "TFLOP/s",
-                         "frac": conv["tflops"] / MFMA_PEAK,
-                         "traffic": None if traffic is None else traffic["fetch_x2"],
-                         "traffic_unit": None if traffic is None else
-                         "HBM bytes per launch: rocprofv3 2 x FETCH_SIZE + WRITE_SIZE (%s); uncorrected %.4g" % (traffic["source"],
-                                                                                                                traffic["raw"]),
-                         "kernel": "conv family (fp32 MFMA implicit GEMM: conv_ws3 / conv_ws / conv_ws16 / conv_mfma)" if not split_mode
-                         else "conv family (split precision: conv_ws3s on the bf16 MFMA, 3 MFMAs per product -- achieved and peak are "
-                              "in fp32-equivalent TFLOP/s, peak = 2516.6 / 3; the f0 models' layers run the fp32 kernels)",
-                         "launches_per_step": conv["launches"] / args.steps,
-                         "algorithmic_tflop_per_step": conv["flops"] / args.steps / 1e12,
-                         "algorithmic_bytes_per_launch": conv["bytes"] / max(1, conv["launches"]),
-                         "kernel_ms_per_step": conv["ms"] / args.steps},
-            "stages": stage_table(conv, sprof.summary(), args.steps),
+                       "wall_split_seconds_per_step": split,
+                       "profiled_step_ms": prof_ms},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if prof is not None:
+            conv = prof.summary()
+            traffic = None if split_mode else pmc_traffic_per_launch()   # the committed PMC passes are of the default (fp32) command
+            res["roofline"] = {
+                "bound": "mfma", "achieved": conv["tflops"], "peak": MFMA_PEAK, "unit": "TFLOP/s",
+                "frac": conv["tflops"] / MFMA_PEAK,
+                "traffic": None if traffic is None else traffic["fetch_x2"],
+                "traffic_unit": None if traffic is None else
+                "HBM bytes per launch: rocprofv3 2 x FETCH_SIZE + WRITE_SIZE (%s); uncorrected %.4g" % (traffic["source"],
+                                                                                                       traffic["raw"]),
+                "kernel": "conv family (fp32 MFMA implicit GEMM: conv_ws3 / conv_ws / conv_ws16 / conv_mfma)" if not split_mode
+                else "conv family (split precision: conv_ws3s on the bf16 MFMA, 3 MFMAs per product -- achieved and peak are "
+                     "in fp32-equivalent TFLOP/s, peak = 2516.6 / 3; the f0 models' layers run the fp32 kernels)",
+                "measured": "HIP events around every launch of one extra step of the same work, taken right behind the timed "
+                            "region (profiled_step_ms; the timed steps carry no events)",
+                "launches_per_step": conv["launches"],
+                "algorithmic_tflop_per_step": conv["flops"] / 1e12,
+                "algorithmic_bytes_per_launch": conv["bytes"] / max(1, conv["launches"]),
+                "kernel_ms_per_step": conv["ms"]}
+            res["stages"] = stage_table(conv, sprof.summary(), 1)
+        else:
+            res["roofline"] = None
+        if world == 1 and not args.no_cpu_baseline and not emu:
             with contextlib.redirect_stdout(sys.stderr):
-                res["cpu_baseline"] = cpu_baseline()
+                res["cpu_baseline"] = dict(cpu_baseline(), **reference_cpu_record())
         if args.dump:
             np.savez_compressed(args.dump, sep=sep.cpu().numpy()[:, ::7], out=out if out is not None else np.zeros(1))
-        print(json.dumps(res))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
     if world > 1:
         td.destroy_process_group()
 
