@@ -186,21 +186,134 @@ __global__ void __launch_bounds__(64) knn8_kernel(const float* __restrict__ dots
     }
 }
 
-// feats[r][c] = rate * sum_k w_k big[idx_k][c] + (1 - rate) * feats[r][c],  w_k = (1 / d_k)^2 / sum_j (1 / d_j)^2
-// (reference :417-431: weight = np.square(1 / score); weight /= weight.sum(axis=1, keepdims=True))
-__global__ void __launch_bounds__(256) index_mix_kernel(float* __restrict__ feats, const float* __restrict__ big, const float* __restrict__ best_d,
-                                                        const long* __restrict__ best_i, int rows, int dim, float rate) {
+// IVF-Flat scan (faiss IndexIVFFlat::search semantics, reference :421 `index.search(npy, k=8)` on an index whose file says
+// nprobe): query r visits the `nprobe` inverted lists probe[r][0..nprobe) (its nearest centroids, nearest first) and keeps the 8
+// smallest squared L2 distances, each computed DIRECTLY as sum_c (q_c - x_c)^2 like faiss' fvec_L2sqr (no |q|^2 - 2 q.x + |x|^2
+// cancellation).  Vectors are stored list by list (vecs[list_off[l] .. list_off[l + 1])), the order of faiss' inverted lists; the
+// result is the POSITION in that storage (the caller maps positions to faiss labels).  A candidate replaces the current 8th only
+// if it is strictly closer, so among equal distances the earlier-scanned one stays -- faiss' max-heap rule.  Lists with fewer than
+// 8 vectors leave distance = +inf, position = -1 (faiss: FLT_MAX / -1; both give weight 0 in the mix).
+// One workgroup of 4 waves per query; wave w takes every 4th vector, a lane 4 consecutive components per 256 (float4 loads).
+__global__ void __launch_bounds__(256) ivf_scan8_kernel(const float* __restrict__ q, const float* __restrict__ vecs,
+                                                        const long* __restrict__ list_off, const long* __restrict__ probe, int probe_ld,
+                                                        int nprobe, int rows, int dim, float* __restrict__ best_d, long* __restrict__ best_pos) {
     const int r = blockIdx.x;
     if (r >= rows) return;
-    float w[8];
-    float sum = 0.f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float inf = __int_as_float(0x7f800000);
+    __shared__ float sd[4][8];
+    __shared__ long sk[4][8], sp[4][8];
+    float d[8];
+    long key[8], pos[8];   // key = position in the query's scan order (the tie-break), pos = position in `vecs`
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { const float inv = 1.f / best_d[(long)r * 8 + k]; w[k] = inv * inv; sum += w[k]; }
+    for (int k = 0; k < 8; ++k) { d[k] = inf; key[k] = 0x7fffffffffffffffL; pos[k] = -1; }
+    const float* qr = q + (long)r * dim;
+    long scanned = 0;   // scan position of the first vector of the current list
+    for (int p = 0; p < nprobe; ++p) {
+        const long l = probe[(long)r * probe_ld + p];
+        if (l < 0) continue;
+        const long b = list_off[l], e = list_off[l + 1];
+        for (long v = b + wave; v < e; v += 4) {
+            const float* x = vecs + v * dim;
+            float acc = 0.f;
+            for (int c = lane * 4; c < dim; c += 256) {
+                const float4 a = *reinterpret_cast<const float4*>(qr + c);
+                const float4 y = *reinterpret_cast<const float4*>(x + c);
+                const float t0 = a.x - y.x, t1 = a.y - y.y, t2 = a.z - y.z, t3 = a.w - y.w;
+                acc += (t0 * t0 + t1 * t1) + (t2 * t2 + t3 * t3);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+            // every lane of the wave now holds the same sum and the same sorted list: uniform insertion, no divergence
+            const long kv = scanned + (v - b);
+            if (acc < d[7] || (acc == d[7] && kv < key[7])) {
+                d[7] = acc; key[7] = kv; pos[7] = v;
+#pragma unroll
+                for (int k = 7; k > 0; --k) {
+                    if (d[k] < d[k - 1] || (d[k] == d[k - 1] && key[k] < key[k - 1])) {
+                        const float tv = d[k]; d[k] = d[k - 1]; d[k - 1] = tv;
+                        const long tk = key[k]; key[k] = key[k - 1]; key[k - 1] = tk;
+                        const long tp = pos[k]; pos[k] = pos[k - 1]; pos[k - 1] = tp;
+                    }
+                }
+            }
+        }
+        scanned += e - b;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { sd[wave][k] = d[k]; sk[wave][k] = key[k]; sp[wave][k] = pos[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // 4-way merge of the waves' sorted lists by (distance, scan position)
+        int h[4] = {0, 0, 0, 0};
+        for (int k = 0; k < 8; ++k) {
+            int bw = -1;
+            for (int w = 0; w < 4; ++w) {
+                if (h[w] >= 8) continue;
+                if (bw < 0 || sd[w][h[w]] < sd[bw][h[bw]] || (sd[w][h[w]] == sd[bw][h[bw]] && sk[w][h[w]] < sk[bw][h[bw]])) bw = w;
+            }
+            best_d[(long)r * 8 + k] = sd[bw][h[bw]];
+            best_pos[(long)r * 8 + k] = sp[bw][h[bw]];
+            ++h[bw];
+        }
+    }
+}
+
+// feats[r][c] = rate * sum_k w_k big[idx_k][c] + (1 - rate) * feats[r][c],  w_k = (1 / d_k)^2 / sum_j (1 / d_j)^2
+// (reference :417-431: weight = np.square(1 / score); weight /= weight.sum(axis=1, keepdims=True)).
+// recompute != 0: the distances are re-evaluated directly, d_k = sum_c (feats[r][c] - big[idx_k][c])^2, before they are used
+// (and written back to best_d): the exhaustive search ranks by |q|^2 - 2 q.x + |x|^2 from a GEMM, whose fp32 cancellation turns
+// near-duplicates into exact zeros; the weights want the direct form faiss computes.
+// idx_k < 0 (fewer than 8 neighbours found): weight 0.  An EXACT zero distance makes the reference's weights inf / inf = NaN; here
+// the zero-distance neighbours share the whole weight instead (the limit of the formula), so one duplicated training frame cannot
+// blank a chunk.
+__global__ void __launch_bounds__(256) index_mix_kernel(float* __restrict__ feats, const float* __restrict__ big, float* __restrict__ best_d,
+                                                        const long* __restrict__ best_i, int rows, int dim, float rate, int recompute) {
+    const int r = blockIdx.x;
+    if (r >= rows) return;
+    __shared__ float sdist[8];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (recompute) {
+        for (int k = wave; k < 8; k += 4) {
+            const long id = best_i[(long)r * 8 + k];
+            float acc = 0.f;
+            if (id >= 0)
+                for (int c = lane; c < dim; c += 64) { const float t = feats[(long)r * dim + c] - big[id * dim + c]; acc += t * t; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+            if (lane == 0) sdist[k] = id >= 0 ? acc : __int_as_float(0x7f800000);
+        }
+    } else if (threadIdx.x < 8) {
+        sdist[threadIdx.x] = best_d[(long)r * 8 + threadIdx.x];
+    }
+    __syncthreads();
+    if (recompute && threadIdx.x < 8) best_d[(long)r * 8 + threadIdx.x] = sdist[threadIdx.x];
+    float w[8];
+    long id[8];
+    float sum = 0.f;
+    int zeros = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        id[k] = best_i[(long)r * 8 + k];
+        const float dk = sdist[k];
+        zeros += (id[k] >= 0 && dk == 0.f) ? 1 : 0;
+        const float inv = id[k] >= 0 ? 1.f / dk : 0.f;
+        w[k] = inv * inv;
+        sum += w[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (zeros) w[k] = (id[k] >= 0 && sdist[k] == 0.f) ? 1.f / (float)zeros : 0.f;
+        else w[k] = w[k] / sum;
+        if (id[k] < 0) id[k] = 0;   // weight 0: any valid row
+    }
     for (int c = threadIdx.x; c < dim; c += 256) {
+        const float f = feats[(long)r * dim + c];
         float acc = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc += big[best_i[(long)r * 8 + k] * dim + c] * (w[k] / sum);
-        feats[(long)r * dim + c] = acc * rate + (1.f - rate) * feats[(long)r * dim + c];
+        for (int k = 0; k < 8; ++k) acc += big[id[k] * dim + c] * w[k];
+        feats[(long)r * dim + c] = acc * rate + (1.f - rate) * f;
     }
 }
 
@@ -267,17 +380,28 @@ extern "C" int aicg_knn8(const float* dots, int64_t ld, const float* xnorm, cons
                          float* best_d, int64_t* best_i, int merge, void* stream) {
     if (!dots || !xnorm || !qnorm || !best_d || !best_i) return fail(AICG_E_ARG, "aicg_knn8: null pointer");
     if (rows <= 0) return AICG_OK;
-    if (cols < 0 || (!merge && cols < 8)) return fail(AICG_E_SHAPE, "aicg_knn8: the first chunk needs at least 8 columns");
+    if (cols < 0) return fail(AICG_E_SHAPE, "aicg_knn8: negative column count");
     hipLaunchKernelGGL(knn8_kernel, dim3((unsigned)rows), dim3(64), 0, (hipStream_t)stream, dots, (long)ld, xnorm, qnorm, rows, cols,
                        (long)col_off, best_d, (long*)best_i, merge);
     return check_launch("knn8_kernel");
 }
 
-extern "C" int aicg_index_mix(float* feats, const float* big, const float* best_d, const int64_t* best_i, int rows, int dim, float rate,
-                              void* stream) {
+extern "C" int aicg_index_mix(float* feats, const float* big, float* best_d, const int64_t* best_i, int rows, int dim, float rate,
+                              int recompute, void* stream) {
     if (!feats || !big || !best_d || !best_i) return fail(AICG_E_ARG, "aicg_index_mix: null pointer");
     if (rows <= 0) return AICG_OK;
     hipLaunchKernelGGL(index_mix_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, feats, big, best_d, (const long*)best_i,
-                       rows, dim, rate);
+                       rows, dim, rate, recompute);
     return check_launch("index_mix_kernel");
+}
+
+extern "C" int aicg_ivf_scan8(const float* q, const float* vecs, const int64_t* list_off, const int64_t* probe, int probe_ld, int nprobe,
+                              int rows, int dim, float* best_d, int64_t* best_pos, void* stream) {
+    if (!q || !vecs || !list_off || !probe || !best_d || !best_pos) return fail(AICG_E_ARG, "aicg_ivf_scan8: null pointer");
+    if (dim < 4 || dim % 4) return fail(AICG_E_SHAPE, "aicg_ivf_scan8: dim must be a positive multiple of 4 (got %d)", dim);
+    if (nprobe < 1 || nprobe > probe_ld) return fail(AICG_E_ARG, "aicg_ivf_scan8: nprobe must be 1..probe_ld");
+    if (rows <= 0) return AICG_OK;
+    hipLaunchKernelGGL(ivf_scan8_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, q, vecs, (const long*)list_off,
+                       (const long*)probe, probe_ld, nprobe, rows, dim, best_d, (long*)best_pos);
+    return check_launch("ivf_scan8_kernel");
 }

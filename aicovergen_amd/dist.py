@@ -19,6 +19,10 @@ import torch.distributed as td
 
 
 def world(group=None):
+    """(rank, world size) of `group` (None = the default group).  The string "single" means: behave as a one-rank job whatever
+    torch.distributed state the process has (a stand-alone f0 call outside VC.pipeline, see VC._f0_group)."""
+    if isinstance(group, str):
+        return 0, 1
     if td.is_available() and td.is_initialized():
         return td.get_rank(group), td.get_world_size(group)
     return 0, 1

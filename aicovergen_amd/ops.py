@@ -577,9 +577,10 @@ def gru_bidir(gi, whh_t, bhh, hidden, two_workgroups=None):
         # the kernel's exchange-timeout flag is read back lazily (gru_check_pending): an .item() here would park the host
         # until the recurrence ends, which is exactly the time pipeline() wants to spend queueing HuBERT work
         _gru_pending.append(scratch[32 * hidden: 32 * hidden + 4].view(torch.int32))
-        if len(_gru_pending) > 16:  # a caller that never checks: bound the backlog (this one synchronises)
-            if gru_timed_out():  # recompute on the kernel that needs no co-residency
-                _call("aicg_gru_bidir", _ptr(gi), _ptr(whh_t), _ptr(bhh), _ptr(out), hidden, t, _stream(gi))
+        if len(_gru_pending) > 16:
+            # a caller that never checks: bound the backlog (this synchronises).  A timeout found here may belong to ANY of the
+            # pending launches, whose outputs were already handed out -- it cannot be repaired from here, so it is an error
+            gru_check_pending()
         return out
     _call("aicg_gru_bidir", _ptr(gi), _ptr(whh_t), _ptr(bhh), _ptr(out), hidden, t, _stream(gi))
     return out
@@ -859,12 +860,26 @@ def knn8_update(dots, xnorm, qnorm, col_off, best_d, best_i, merge):
           _ptr(best_d), _ptr(best_i), 1 if merge else 0, _stream(dots))
 
 
-def index_mix_(feats, big, best_d, best_i, rate):
-    """feats (rows, dim) <- rate * sum_k w_k big[best_i[k]] + (1 - rate) * feats, w = inverse-square-distance weights."""
-    assert feats.is_contiguous() and big.is_contiguous()
+def ivf_scan8(feats, vecs, list_off, probe, nprobe):
+    """IndexIVFFlat scan: feats (rows, dim), vecs (N, dim) stored list by list, list_off (nlist + 1,) int64, probe (rows, >= nprobe)
+    int64 nearest-first list ids -> (squared distances (rows, 8) ascending, storage positions (rows, 8), -1 where none)."""
+    assert feats.is_contiguous() and vecs.is_contiguous() and probe.is_contiguous() and list_off.dtype == torch.int64
+    rows, dim = feats.shape
+    best_d = torch.empty((rows, 8), dtype=torch.float32, device=feats.device)
+    best_p = torch.empty((rows, 8), dtype=torch.int64, device=feats.device)
+    _check(feats, vecs, list_off, probe)
+    _call("aicg_ivf_scan8", _ptr(feats), _ptr(vecs), _ptr(list_off), _ptr(probe), probe.shape[1], int(nprobe), rows, dim,
+          _ptr(best_d), _ptr(best_p), _stream(feats))
+    return best_d, best_p
+
+
+def index_mix_(feats, big, best_d, best_i, rate, recompute=False):
+    """feats (rows, dim) <- rate * sum_k w_k big[best_i[k]] + (1 - rate) * feats, w = inverse-square-distance weights (best_i < 0:
+    weight 0).  `recompute`: distances re-evaluated directly from the gathered rows first (and stored in best_d)."""
+    assert feats.is_contiguous() and big.is_contiguous() and best_d.is_contiguous() and best_i.is_contiguous()
     _check(feats, big, best_d, best_i)
     _call("aicg_index_mix", _ptr(feats), _ptr(big), _ptr(best_d), _ptr(best_i), feats.shape[0], feats.shape[1], float(rate),
-          _stream(feats))
+          1 if recompute else 0, _stream(feats))
     return feats
 
 

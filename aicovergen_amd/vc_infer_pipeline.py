@@ -26,6 +26,8 @@ bh, ah = signal.butter(N=5, Wn=48, btype="high", fs=16000)  # reference :22
 
 input_audio_path2wav = {}
 
+_NO_GROUP = "single"   # sentinel understood by dist.world(): this call must not communicate even if a process group exists
+
 
 def _rms_frames(y, frame_length, hop_length):
     """librosa.feature.rms(y=y, frame_length=, hop_length=) of librosa 0.9.1: center=True with reflect padding,
@@ -51,7 +53,7 @@ def change_rms(data1, sr1, data2, sr2, rate):
 
 
 def _bracket_pipeline(fn):
-    """While VC.pipeline runs, the f0 estimators may use the job's process group (VC._rmvpe_group) -- and never outside it,
+    """While VC.pipeline runs, the f0 estimators may use the job's process group (VC._f0_group) -- and never outside it,
     whatever happens inside the call."""
     @functools.wraps(fn)
     def wrapper(self, *args, **kwargs):
@@ -60,6 +62,7 @@ def _bracket_pipeline(fn):
             return fn(self, *args, **kwargs)
         finally:
             self._in_pipeline = False
+            self._group = None
     return wrapper
 
 
@@ -89,7 +92,7 @@ class VC(object):
         injected as `self.model_crepe[model]` (tests / benchmarks use seeded parameters)."""
         from . import crepe
         print("Initiating prediction with a crepe_hop_length of: " + str(hop_length))
-        return crepe.mangio_crepe_f0(self._crepe(model), x, p_len, hop_length, dither=dither, group=getattr(self, "_group", None))
+        return crepe.mangio_crepe_f0(self._crepe(model), x, p_len, hop_length, dither=dither, group=self._f0_group(False))
 
     def _crepe(self, model):
         from . import crepe
@@ -104,7 +107,7 @@ class VC(object):
         median of the periodicity, 3-frame mean of f0, unvoiced (periodicity < 0.1) frames zeroed."""
         from . import crepe
         return crepe.official_crepe_f0(self._crepe(model), x, self.window, f0_min, f0_max, dither=dither,
-                                       group=getattr(self, "_group", None))
+                                       group=self._f0_group(False))
 
     def get_f0_hybrid_computation(self, methods_str, input_audio_path, x, f0_min, f0_max, p_len, filter_radius,
                                   crepe_hop_length, time_step):
@@ -131,16 +134,22 @@ class VC(object):
             return stack[0]
         return np.nanmedian(stack, axis=0)   # like the reference, estimators of different lengths raise here
 
-    def _rmvpe_group(self):
-        """Inside pipeline() the ranks of the job cut RMVPE's U-Net over time (rmvpe.E2E.features_sharded); a stand-alone
-        get_f0 call (no pipeline in progress) never communicates."""
+    def _f0_group(self, explicit=True):
+        """The process group the f0 estimators may communicate over.  Inside pipeline() the ranks of the job cut RMVPE's U-Net
+        over time (rmvpe.E2E.features_sharded) and CREPE's frames (crepe.predict); a stand-alone get_f0 /
+        get_f0_*_computation call (no pipeline in progress) NEVER communicates, whatever torch.distributed state the process
+        has -- the other ranks would not join the collective.
+        Returns None outside pipeline() or for a single-rank job.  Inside: the job's group; for the default group that is
+        td.group.WORLD when `explicit` (RMVPE tests `group is not None`) and None otherwise (crepe hands it to dist.world())."""
         import torch.distributed as td
         if not getattr(self, "_in_pipeline", False) or not (td.is_available() and td.is_initialized()):
-            return None
+            return _NO_GROUP if not explicit else None
         g = getattr(self, "_group", None)
         if (td.get_world_size(g) if g is not None else td.get_world_size()) < 2:
-            return None
-        return g if g is not None else td.group.WORLD
+            return _NO_GROUP if not explicit else None
+        return g if (g is not None or not explicit) else td.group.WORLD
+
+    _rmvpe_group = _f0_group
 
     def _rmvpe(self):
         if not hasattr(self, "model_rmvpe"):
@@ -226,7 +235,8 @@ class VC(object):
         feats = model.final_proj(logits[0]) if version == "v1" else logits[0]
         feats0 = feats.clone() if use_protect else None
         if index is not None and hasattr(index, "mix_") and index_rate != 0:
-            # device retrieval (aicovergen_amd.retrieval.FeatureIndex): exact k = 8 search + inverse-square blend in HBM
+            # device retrieval (aicovergen_amd.retrieval.FeatureIndex): faiss' search for the file's index type (IVF-Flat with
+            # its nprobe, or flat) + inverse-square blend, all in HBM
             feats = index.mix_(feats[0].contiguous(), index_rate).unsqueeze(0)
         elif index is not None and big_npy is not None and index_rate != 0:
             npy = feats[0].cpu().numpy().astype("float32")

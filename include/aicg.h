@@ -298,16 +298,27 @@ int aicg_filtfilt_f64(const double* x, double* y, int64_t n, const double* b, co
 int aicg_resample_poly(const float* x, float* y, int64_t n_in, int64_t n_out, int n_channels, int64_t x_sc, int up, int down,
                        const float* hp, int taps, int64_t pre, void* stream);
 
-/* Retrieval mix of VC.vc (src/vc_infer_pipeline.py:409-431: index.search(npy, k=8), inverse-square weights, blend):
+/* Retrieval mix of VC.vc (src/vc_infer_pipeline.py:409-431: index.search(npy, k=8), inverse-square weights, blend; the index is
+ * the faiss IVF-Flat file read at :497-512):
  * aicg_row_sqnorm: |v_r|^2 of a (rows, dim) matrix;
- * aicg_knn8: exact 8 nearest neighbours by squared L2 distance from inner products dots[r][c] (row stride ld) of one column
- *   chunk [col_off, col_off + cols) of the index, merged into best_d / best_i (rows x 8, ascending) when merge != 0;
- * aicg_index_mix: feats = rate * sum_k w_k big[best_i[k]] + (1 - rate) * feats with w = (1/d)^2 / sum (1/d)^2. */
+ * aicg_knn8: the 8 nearest columns by squared L2 distance |q|^2 - 2 q.x + |x|^2 from inner products dots[r][c] (row stride ld) of
+ *   one column chunk [col_off, col_off + cols), merged into best_d / best_i (rows x 8, ascending, ties by lower column) when
+ *   merge != 0; fewer than 8 columns in total leave distance +inf / index INT64_MAX.  Serves the coarse quantizer (columns =
+ *   centroids: faiss IndexFlatL2's BLAS search uses the same expansion) and the opt-in exhaustive search (columns = all vectors);
+ * aicg_ivf_scan8: IndexIVFFlat::search -- query r scans inverted lists probe[r][0..nprobe) (row stride probe_ld) of vectors
+ *   stored list by list (list l = vecs[list_off[l] .. list_off[l + 1])), distances computed directly as sum (q - x)^2, the 8
+ *   smallest kept (a later candidate must be strictly closer: faiss' heap rule); best_pos = position in `vecs`, -1 / +inf when
+ *   fewer than 8 vectors were visited;
+ * aicg_index_mix: feats = rate * sum_k w_k big[best_i[k]] + (1 - rate) * feats with w = (1/d)^2 / sum (1/d)^2; best_i < 0 gets
+ *   weight 0; exact-zero distances share the whole weight (the reference divides inf by inf there); recompute != 0 re-evaluates
+ *   d_k = sum (feats - big[best_i[k]])^2 first and stores it in best_d. */
 int aicg_row_sqnorm(const float* v, float* out, int64_t rows, int dim, void* stream);
 int aicg_knn8(const float* dots, int64_t ld, const float* xnorm, const float* qnorm, int rows, int cols, int64_t col_off,
               float* best_d, int64_t* best_i, int merge, void* stream);
-int aicg_index_mix(float* feats, const float* big, const float* best_d, const int64_t* best_i, int rows, int dim, float rate,
-                   void* stream);
+int aicg_ivf_scan8(const float* q, const float* vecs, const int64_t* list_off, const int64_t* probe, int probe_ld, int nprobe,
+                   int rows, int dim, float* best_d, int64_t* best_pos, void* stream);
+int aicg_index_mix(float* feats, const float* big, float* best_d, const int64_t* best_i, int rows, int dim, float rate,
+                   int recompute, void* stream);
 
 #ifdef __cplusplus
 }

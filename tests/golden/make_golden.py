@@ -1,5 +1,5 @@
 """Regenerate tests/golden/*.npz by running the REFERENCE ITSELF (imported from /root/reference/src, build
-container only) on seeded parameters from oracle/weights.py and seeded inputs.  The fixtures pin the oracle
+container only) on seeded parameters from synthetic/weights.py and seeded inputs.  The fixtures pin the oracle
 (tests/test_oracle_golden.py) and travel to the GPU box, where /root/reference does not exist.
 
     python tests/golden/make_golden.py
@@ -38,8 +38,8 @@ def injected_noise(draws):
 def make_synth(name, cfg, T, seed, variant="768f0"):
     sys.path.insert(0, REF)
     from infer_pack import models as ref_models
-    from oracle import weights
-    from oracle.inputs import synth_inputs
+    from synthetic import weights
+    from synthetic.inputs import synth_inputs
     phone_dim, f0_on = (256 if variant.startswith("256") else 768), variant.endswith("f0")
     sd = weights.synth_state_dict(cfg, seed, phone_dim=phone_dim, f0=f0_on)
     cls = {"768f0": "SynthesizerTrnMs768NSFsid", "256f0": "SynthesizerTrnMs256NSFsid", "768nono": "SynthesizerTrnMs768NSFsid_nono",
@@ -66,8 +66,8 @@ def make_hubert(name, cfg, seconds, seed):
     """HuBERT: fairseq is absent, so the pin is transformers.HubertModel with the same weights (key-mapped)."""
     from transformers import HubertConfig, HubertModel
     from oracle import hubert as ohub
-    from oracle import weights
-    from oracle.inputs import vocal_like
+    from synthetic import weights
+    from synthetic.inputs import vocal_like
     sd = weights.hubert_state_dict(cfg, seed)
     hc = HubertConfig(hidden_size=cfg["embed"], num_hidden_layers=cfg["layers"], num_attention_heads=cfg["heads"],
                       intermediate_size=cfg["ffn"], conv_dim=(cfg["conv_dim"],) * 7, num_conv_pos_embeddings=cfg["pos_k"],
@@ -87,8 +87,8 @@ def make_hubert(name, cfg, seconds, seed):
 def make_rmvpe(name, cfg, seconds, seed):
     import types
     from oracle import rmvpe as orm
-    from oracle import weights
-    from oracle.inputs import vocal_like
+    from synthetic import weights
+    from synthetic.inputs import vocal_like
     lib = types.ModuleType("librosa")
     lib.filters = types.ModuleType("librosa.filters")
     lib.filters.mel = lambda sr, n_fft, n_mels, fmin, fmax, htk: orm.mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
@@ -126,8 +126,8 @@ def make_pipeline(name, seconds, seed, full=False, x=(1, 1, 1, 2)):
     from oracle import hubert as ohub
     from oracle import pipeline as opipe
     from oracle import rmvpe as orm
-    from oracle import weights
-    from oracle.inputs import vocal_like
+    from synthetic import weights
+    from synthetic.inputs import vocal_like
     np.int = int  # removed alias used at vc_infer_pipeline.py:368
     for mod in ("faiss", "parselmouth", "pyworld", "torchcrepe"):
         sys.modules.setdefault(mod, types.ModuleType(mod))
@@ -207,7 +207,7 @@ def make_pipeline(name, seconds, seed, full=False, x=(1, 1, 1, 2)):
 
 
 if __name__ == "__main__":
-    from oracle import weights
+    from synthetic import weights
     if len(sys.argv) > 1 and sys.argv[1] == "c1":
         # BASELINE config C1: 30 s mono 16 kHz through the reference's own VC.pipeline on the CPU, full-size networks,
         # main.py's chunk preset (one 576 000-sample padded chunk)

@@ -20,7 +20,8 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
-from oracle import mdxnet, weights  # noqa: E402
+from oracle import mdxnet  # noqa: E402
+from synthetic import weights
 from synthetic.inputs import song_like  # noqa: E402
 
 CFG = dict(weights.MDX_TINY, n_fft=2048, dim_t=16)

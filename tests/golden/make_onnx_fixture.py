@@ -10,7 +10,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from oracle import mdxnet, weights  # noqa: E402
+from oracle import mdxnet  # noqa: E402
+from synthetic import weights
 
 
 def export_unet(sd, cfg, path=None):

@@ -1,5 +1,5 @@
 """Signal-processing kernels either side of the networks (csrc/dsp.hip) against numpy / scipy:
-3-tap NaN-aware median / mean, zero-phase IIR (filtfilt), polyphase resampling, exact k = 8 retrieval + mix."""
+3-tap NaN-aware median / mean, zero-phase IIR (filtfilt), polyphase resampling (retrieval: tests/test_retrieval.py)."""
 import numpy as np
 import pytest
 import torch
@@ -93,74 +93,3 @@ def test_resample_poly_matches_scipy(dev):
         got = ops.resample_poly_mono(dev.t(torch.from_numpy(x)), sr_in, sr_out).cpu().numpy()
         assert got.shape == want.shape
         assert np.abs(got - want).max() < 2e-6 * np.abs(want).max(), (sr_in, sr_out)
-
-
-def test_knn8_and_mix(dev):
-    """Exact 8 nearest neighbours by squared L2 (ties by lower id), chunked over the index, and the inverse-square blend
-    (vc_infer_pipeline.py:415-431 with a brute-force search)."""
-    rng = np.random.default_rng(3)
-    n, dim, t = 3000, 64, 37
-    big = rng.standard_normal((n, dim)).astype(np.float32)
-    big[100] = big[7]                                           # an exact duplicate: tie broken by id
-    feats = rng.standard_normal((t, dim)).astype(np.float32)
-    feats[3] = big[7] + 1e-3
-    old = retrieval.CHUNK
-    retrieval.CHUNK = 1024                                      # three column chunks, the last one ragged
-    try:
-        idx = retrieval.FeatureIndex(big, dev.device)
-        d, i = idx.search(dev.t(torch.from_numpy(feats)))
-        d64 = ((feats[:, None, :].astype(np.float64) - big[None].astype(np.float64)) ** 2).sum(-1)
-        order = np.lexsort((np.arange(n)[None].repeat(t, 0), d64), axis=1)[:, :8]
-        got_i = i.cpu().numpy()
-        want_d = np.take_along_axis(d64, order, 1)
-        # ids agree wherever the gap to the next candidate is not within fp32 noise of the GEMM formulation
-        gap = np.take_along_axis(d64, np.lexsort((np.arange(n)[None].repeat(t, 0), d64), axis=1)[:, 1:9], 1) - want_d
-        firm = gap > 1e-3
-        assert (got_i[firm] == order[firm]).all()
-        assert np.allclose(d.cpu().numpy(), want_d, rtol=1e-4, atol=1e-3)
-        assert got_i[3, 0] == 7 and got_i[3, 1] == 100
-        f = dev.t(torch.from_numpy(feats.copy()))
-        mixed = idx.mix_(f, 0.6).cpu().numpy()
-        dd = d.cpu().numpy().astype(np.float64)
-        w = np.square(1 / dd)
-        w /= w.sum(1, keepdims=True)
-        want = (big[got_i] * w[:, :, None]).sum(1) * 0.6 + 0.4 * feats
-        assert np.abs(mixed - want).max() < 1e-4 * np.abs(want).max()
-    finally:
-        retrieval.CHUNK = old
-
-
-def _write_ivf_flat(path, vecs, nlist=4):
-    """A faiss IndexIVFFlat file as faiss' index_write.cpp lays it out (restated; see aicovergen_amd/retrieval.py)."""
-    import struct
-    n, d = vecs.shape
-    assign = np.arange(n) % nlist
-    out = bytearray()
-
-    def hdr(dd, nt):
-        return struct.pack("<iqqqBi", dd, nt, 1 << 20, 1 << 20, 1, 1)
-    out += b"IwFl" + hdr(d, n) + struct.pack("<QQ", nlist, 1)
-    cent = np.stack([vecs[assign == k].mean(0) for k in range(nlist)]).astype(np.float32)
-    out += b"IxF2" + hdr(d, nlist) + struct.pack("<Q", cent.size) + cent.tobytes()
-    out += struct.pack("<B", 0) + struct.pack("<Q", 0)
-    out += b"ilar" + struct.pack("<QQ", nlist, 4 * d) + b"full"
-    sizes = np.array([(assign == k).sum() for k in range(nlist)], dtype=np.uint64)
-    out += struct.pack("<Q", nlist) + sizes.tobytes()
-    for k in range(nlist):
-        ids = np.nonzero(assign == k)[0].astype(np.int64)
-        out += vecs[ids].astype(np.float32).tobytes() + ids.tobytes()
-    open(path, "wb").write(bytes(out))
-
-
-def test_index_file_readers(tmp_path, dev):
-    rng = np.random.default_rng(4)
-    vecs = rng.standard_normal((50, 16)).astype(np.float32)
-    p = tmp_path / "added.index"
-    _write_ivf_flat(str(p), vecs)
-    assert np.array_equal(retrieval.read_faiss_vectors(str(p)), vecs)
-    np.save(tmp_path / "total_fea.npy", vecs)
-    idx = retrieval.load_index(str(tmp_path / "total_fea.npy"), dev.device)
-    assert idx.ntotal == 50 and idx.dim == 16
-    (tmp_path / "bad.index").write_bytes(b"IxPQ" + b"\0" * 64)
-    with pytest.raises(ValueError):
-        retrieval.read_faiss_vectors(str(tmp_path / "bad.index"))

@@ -13,8 +13,8 @@ from aicovergen_amd.rmvpe import RMVPE, mel_filterbank
 from conftest import rel_rms
 from oracle import hubert as ohub
 from oracle import rmvpe as orm
-from oracle import weights
-from oracle.inputs import vocal_like
+from synthetic import weights
+from synthetic.inputs import vocal_like
 
 
 def test_hubert_tiny_matches_oracle(dev):

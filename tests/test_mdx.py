@@ -7,8 +7,9 @@ import torch
 from aicovergen_amd.mdx import MDX, MDXModel, run_mdx_arrays
 from aicovergen_amd.mdx_net import ConvTDFNet
 from conftest import rel_rms
-from oracle import mdxnet, weights
-from oracle.inputs import song_like
+from oracle import mdxnet
+from synthetic import weights
+from synthetic.inputs import song_like
 
 
 def _session(dev, cfg=weights.MDX_TINY, hop=64, seed=1234):

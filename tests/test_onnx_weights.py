@@ -12,7 +12,8 @@ import torch
 from aicovergen_amd import onnx_weights
 from aicovergen_amd.mdx_net import ConvTDFNet, infer_cfg
 from conftest import rel_rms
-from oracle import mdxnet, weights
+from oracle import mdxnet
+from synthetic import weights
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 FIXTURE = os.path.join(GOLD, "mdx_tiny.onnx")

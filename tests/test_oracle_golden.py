@@ -9,8 +9,9 @@ import torch
 from conftest import rel_rms
 from oracle import hubert as ohub
 from oracle import rmvpe as orm
-from oracle import synth, weights
-from oracle.inputs import synth_inputs, vocal_like
+from oracle import synth
+from synthetic import weights
+from synthetic.inputs import synth_inputs, vocal_like
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 

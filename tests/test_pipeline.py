@@ -13,8 +13,8 @@ from aicovergen_amd.rmvpe import RMVPE
 from aicovergen_amd.vc_infer_pipeline import VC, Pipeline, change_rms
 from conftest import rel_rms
 from oracle import pipeline as opipe
-from oracle import weights
-from oracle.inputs import vocal_like
+from synthetic import weights
+from synthetic.inputs import vocal_like
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 

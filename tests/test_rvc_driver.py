@@ -5,8 +5,8 @@ import torch
 from scipy.io import wavfile
 
 from aicovergen_amd import rvc
-from oracle import weights
-from oracle.inputs import vocal_like
+from synthetic import weights
+from synthetic.inputs import vocal_like
 
 
 def _write_models(tmp_path, nets):

@@ -10,8 +10,9 @@ import torch
 
 from aicovergen_amd.infer_pack.models import SynthesizerTrnMs768NSFsid
 from conftest import rel_rms
-from oracle import synth, weights
-from oracle.inputs import synth_inputs
+from oracle import synth
+from synthetic import weights
+from synthetic.inputs import synth_inputs
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 

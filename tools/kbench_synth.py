@@ -4,8 +4,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from aicovergen_amd.infer_pack.models import SynthesizerTrnMs768NSFsid
-from oracle import weights
-from oracle.inputs import synth_inputs
+from synthetic import weights
+from synthetic.inputs import synth_inputs
 cfg = weights.SYNTH_CFG_40K_V2
 net = SynthesizerTrnMs768NSFsid(*cfg, is_half=False); del net.enc_q
 net.load_state_dict(weights.synth_state_dict(cfg, 1234), strict=False); net.eval().to("cuda:0")
