@@ -234,7 +234,8 @@ class PackedConv:
         self.stride, self.padding, self.dilation = stride, padding, dilation
         device = weight.device if device is None else device
         self.split = bool(split_precision)
-        self.frozen_narrow = bool(_fp32_depth)   # packed inside fp32_layers(): an f0 model (aicg_conv_desc.frozen_narrow)
+        # packed inside fp32_layers(): an f0 model (aicg_conv_desc.frozen_narrow); AICG_FROZEN_NARROW=0: A/B switch of tools/c1_triangulate.py
+        self.frozen_narrow = bool(_fp32_depth) and os.environ.get("AICG_FROZEN_NARROW", "1") != "0"
         self.w = pack_conv_weight(weight.to(device), groups, self.split)
         self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
 

@@ -87,8 +87,9 @@ def vc_chunk(nets, geo, audio0, pitch, pitchf, sid, protect, noise):
 
 
 def chunk_noise(ci, T, inter, upp, seed):
-    g = torch.Generator().manual_seed(seed * 1000 + ci)
-    return torch.randn(1, inter, T, generator=g), torch.randn(1, T * upp, generator=g)
+    g = torch.Generator().manual_seed(seed * 1000 + ci)   # float32 draws whatever the default dtype (make_fp64_c1.py casts them)
+    return (torch.randn(1, inter, T, generator=g, dtype=torch.float32).to(torch.get_default_dtype()),
+            torch.randn(1, T * upp, generator=g, dtype=torch.float32).to(torch.get_default_dtype()))
 
 
 def chunk_frames(n_samples):

@@ -31,7 +31,7 @@ def log_mel(audio, mel_basis):
     fft = torch.stft(audio, n_fft=1024, hop_length=160, win_length=1024, window=torch.hann_window(1024), center=True,
                      return_complex=True)
     mag = torch.sqrt(fft.real.pow(2) + fft.imag.pow(2))
-    return torch.log(torch.clamp(torch.matmul(mel_basis, mag), min=1e-5))
+    return torch.log(torch.clamp(torch.matmul(mel_basis.to(mag.dtype), mag), min=1e-5))   # the table itself is float32 (librosa)
 
 
 def _bn_eval(x, sd, name, eps=1e-5):
