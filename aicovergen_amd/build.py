@@ -30,12 +30,32 @@ def _newer(target, deps):
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def build_hip(force=False, verbose=True):
-    """Compile every csrc/*.hip for gfx950 and link libaicg_hip.so next to this file."""
+def build_hip(force=False, verbose=True, dev=False):
+    """Compile every csrc/*.hip for gfx950 and link libaicg_hip.so next to this file.
+    dev=True builds libaicg_hip_dev.so instead, with -DAICG_DEV_SWITCHES: the environment-controlled A/B switches and the kernel
+    generations only they select (csrc/common.h AICG_SWITCH) -- for tools/, bound through _lib._use_library_for_tests; the product
+    never loads it."""
+    global OUT, OBJ_DIR
+    if dev:
+        return _with_paths(os.path.join(HERE, "libaicg_hip_dev.so"), os.path.join(HERE, "build_dev"), force, verbose)
+    return _build(force, verbose, False)
+
+
+def _with_paths(out, obj_dir, force, verbose):
+    global OUT, OBJ_DIR
+    old = OUT, OBJ_DIR
+    OUT, OBJ_DIR = out, obj_dir
+    try:
+        return _build(force, verbose, True)
+    finally:
+        OUT, OBJ_DIR = old
+
+
+def _build(force, verbose, dev):
     hipcc = _hipcc()
     os.makedirs(OBJ_DIR, exist_ok=True)
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-constant-logical-operand"] + (["-DAICG_DEV_SWITCHES"] if dev else [])
     jobs = []
     objs = []
     for src in sources():
@@ -56,16 +76,16 @@ def build_hip(force=False, verbose=True):
                 raise RuntimeError("hipcc failed: %s\n%s" % (" ".join(cmd), log))
     if jobs or force or not os.path.exists(OUT):
         # link inside build/ (clang-offload-bundler drops its per-object temporaries next to the output), then move
-        tmp = os.path.join(OBJ_DIR, "libaicg_hip.so")
+        tmp = os.path.join(OBJ_DIR, os.path.basename(OUT))
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
         r = subprocess.run(cmd, capture_output=True, text=True, cwd=OBJ_DIR)
         if r.returncode != 0:
             raise RuntimeError("link failed: %s\n%s" % (" ".join(cmd), r.stdout + r.stderr))
         os.replace(tmp, OUT)
-        for f in glob.glob(os.path.join(OBJ_DIR, "libaicg_hip.so.*")) + glob.glob(os.path.join(HERE, "libaicg_hip.so.*")):
+        for f in glob.glob(os.path.join(OBJ_DIR, os.path.basename(OUT) + ".*")) + glob.glob(OUT + ".*"):
             os.remove(f)
     return OUT
 
 
 if __name__ == "__main__":
-    print(build_hip(force="--force" in sys.argv))
+    print(build_hip(force="--force" in sys.argv, dev="--dev" in sys.argv))

@@ -7,6 +7,16 @@
 
 #include "../../include/aicg.h"
 
+// A/B switches.  Development builds (-DAICG_DEV_SWITCHES: the CPU emulator of tests/emu, tools/'s private library) read them from
+// the environment once; in the product library they are compile-time constants -- the dispatcher carries no getenv and the kernel
+// generations only a non-default switch can select are not linked.
+#ifdef AICG_DEV_SWITCHES
+#include <cstdlib>
+#define AICG_SWITCH(var, name, dflt) static const long var = getenv(name) ? atol(getenv(name)) : (long)(dflt)
+#else
+#define AICG_SWITCH(var, name, dflt) constexpr long var = (long)(dflt)
+#endif
+
 namespace aicg {
 
 // error plumbing: the C ABI returns negative codes and keeps a per-thread message for aicg_last_error()

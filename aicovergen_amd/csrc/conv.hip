@@ -146,7 +146,7 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
 
     // pointwise streaming form: 1x1, unit stride, no padding, <= 8 channels on one side, float4-aligned rows
     {
-        static const bool pointwise = getenv("AICG_CONV_POINTWISE") ? atoi(getenv("AICG_CONV_POINTWISE")) != 0 : true;
+        AICG_SWITCH(pointwise, "AICG_CONV_POINTWISE", 1);
         const bool few_in = p.Cin_g <= 8, few_out = p.Cout_g <= 8;
         auto al4 = [](long v) { return (v & 3) == 0; };
         const bool aligned = (Wo & 3) == 0 && al4(p.x_sn) && al4(p.x_sc) && al4(p.x_sh) && al4(p.y_sn) && al4(p.y_sc) && al4(p.y_sh) &&
@@ -177,11 +177,11 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
     }
     const long npos = (long)p.N * Ho * Wo;
     hipStream_t st = (hipStream_t)stream;
-    static const int ablate = getenv("AICG_CONV_ABLATE") ? atoi(getenv("AICG_CONV_ABLATE")) : 0;
+    AICG_SWITCH(ablate, "AICG_CONV_ABLATE", 0);
     p.dbg = ablate;
     auto blocks = [&](int bm, int bn) { return (long)idiv_up(M, bm) * p.groups * ldiv_up(npos, bn); };
     // (AICG_CONV_WANT: tests lower the fill target so that small problems exercise the large tiles on the CPU emulator)
-    static const long want = getenv("AICG_CONV_WANT") ? atol(getenv("AICG_CONV_WANT")) : 512;
+    AICG_SWITCH(want, "AICG_CONV_WANT", 512);
     // opt-in split precision (aicg_conv_desc.split, conv_ws3s.h): no 160-row tile there (5 x 16 accumulators leave no room for
     // hi + lo fragments), those layers take the least-padded of the other tiles
     if (p.wsplit && p.Cin_g >= 16 && M > 16) {
@@ -214,19 +214,23 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
         if (rc <= 0) return rc;
     }
     // narrow layers (16 / 48 output channels, at least 3 input channels, enough positions): 16x16x4 MFMA tiles
-    static const bool use16 = getenv("AICG_CONV_M16") ? atoi(getenv("AICG_CONV_M16")) != 0 : true;
+    AICG_SWITCH(use16, "AICG_CONV_M16", 1);
     // (measured r2: MDX level 0 97 vs 105 TFLOP/s, RMVPE level 0 57 vs 60 against conv_ws16_kernel -- 12 MFMAs per k-step already
     //  amortise the fragment hand-over there, and the 16-channel groups need the larger patch: off by default)
-    static const int v3m16 = getenv("AICG_CONV_V3M16") ? atoi(getenv("AICG_CONV_V3M16")) : 0;
+    AICG_SWITCH(v3m16, "AICG_CONV_V3M16", 0);
+#ifdef AICG_DEV_SWITCHES
     if (use16 && v3m16 && p.w3 && p.Cin_g >= 16 && npos >= 256L * 256) {
         int rc = 1;
         if (M > 32 && M <= 48) rc = run_ws3m16_48(p, (hipStream_t)stream);
         else if (M <= 16) rc = run_ws3m16_16(p, (hipStream_t)stream);
         if (rc <= 0) return rc;
     }
+#else
+    (void)v3m16;
+#endif
     // 8-byte fragments (conv_ws3m16h_kernel): the same 8-row K groups as the 32 x 32 kernels, half the hand-overs of conv_ws16_kernel
-    static const int m16h = getenv("AICG_CONV_M16H") ? atoi(getenv("AICG_CONV_M16H")) : 1;
-    if (use16 && m16h && !d->frozen_narrow && p.w3 && p.Cin_g >= 8 && npos >= 256L * 256) {
+    AICG_SWITCH(m16h, "AICG_CONV_M16H", 1);
+    if (use16 && m16h && p.w3 && p.Cin_g >= 8 && npos >= 256L * 256) {
         int rc = 1;
         if (M > 32 && M <= 48) rc = run_ws3m16h_48(p, st);
         else if (M <= 16) rc = run_ws3m16h_16(p, st);
@@ -240,12 +244,12 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
     }
     // A launch should give each of the 256 CUs at least ~2 workgroups: shrink the tile for small problems
     // (HuBERT / enc_p GEMMs over a few thousand frames), M first (keeps the wide, coalesced N tile), then N.
-    static const int ws = getenv("AICG_CONV_WS") ? atoi(getenv("AICG_CONV_WS")) : 1;
+    AICG_SWITCH(ws, "AICG_CONV_WS", 1);
     // 16-byte-fragment kernels (conv_ws3.h): layers with >= 8 input channels per group
-    static const int v3 = getenv("AICG_CONV_V3") ? atoi(getenv("AICG_CONV_V3")) : 1;
+    AICG_SWITCH(v3, "AICG_CONV_V3", 1);
     if (ws && v3 && p.w3 && p.Cin_g >= 8) {
         int rc = 1;
-        static const int v3_160 = getenv("AICG_CONV_V3_160") ? atoi(getenv("AICG_CONV_V3_160")) : 1;
+        AICG_SWITCH(v3_160, "AICG_CONV_V3_160", 1);
         // (the shuffle / multiplicative-skip instantiation of the 160-row tile spills inside its K loop: those layers stay classic)
         if (BM == 160 && v3_160 && !p.shuffle && !p.res_mul && blocks(160, 128) >= want) rc = run_ws3_160x128(p, st);
         else if (BM == 128 && blocks(128, 128) >= want) rc = run_ws3_128x128(p, st);
@@ -262,16 +266,20 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
     if (ws) {
         int rc = 1;
         // v2 shapes: four MFMAs per consumer k-step (r2 timeline: the K loop of the 2-MFMA shapes keeps the matrix pipe 66 % busy)
-        static const int v2 = getenv("AICG_CONV_V2") ? atoi(getenv("AICG_CONV_V2")) : 0;
+        AICG_SWITCH(v2, "AICG_CONV_V2", 0);
+#ifdef AICG_DEV_SWITCHES
         if (v2 & 1) { if (BM == 128 && blocks(128, 128) >= want) rc = run_ws_128x128_k32(p, st); }
         if (rc == 1 && (v2 & 2)) { if (M > 32 && M <= 64 && blocks(64, 256) >= want) rc = run_ws_64x256(p, st); }
         if (rc == 1 && (v2 & 4)) { if (M <= 32 && blocks(32, 512) >= want) rc = run_ws_32x512(p, st); }
         if (rc <= 0) return rc;
+#else
+        (void)v2;
+#endif
         if (BM == 160 && blocks(160, 128) >= want) rc = run_ws_160x128(p, st);
         else if (BM == 128 && blocks(128, 128) >= want) {
             // >= 2 M tiles of 128: four-consumer 64-row tiles (two workgroups per CU overlap their prologue / epilogue) measured
             // 7 % faster than the one-per-CU 128 x 128 shape on the 256-channel vocoder stage; a single 128-row tile keeps the latter
-            static const int bm128e = getenv("AICG_CONV_BM128") ? atoi(getenv("AICG_CONV_BM128")) : 0;
+            AICG_SWITCH(bm128e, "AICG_CONV_BM128", 0);
             const bool use64 = bm128e ? bm128e == 64 : M >= 256;
             rc = use64 ? run_ws_64x128(p, st) : run_ws_128x128(p, st);
         }
@@ -279,7 +287,7 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
         else if (M > 32 && blocks(64, 128) >= want) rc = run_ws_64x128(p, st);
         if (rc <= 0) return rc;
         // small problems (few output positions: HuBERT / enc_p / flow GEMMs) and 32-channel layers: the same kernel on smaller tiles
-        static const int smallws = getenv("AICG_CONV_SMALLWS") ? atoi(getenv("AICG_CONV_SMALLWS")) : 1;
+        AICG_SWITCH(smallws, "AICG_CONV_SMALLWS", 1);
         if (smallws) {
             if (M > 32) {
                 if (!(blocks(64, 128) >= want) && (blocks(64, 64) >= want || M > 64)) rc = run_ws_64x64(p, st);
@@ -290,10 +298,15 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
     }
     // single-role kernels: layers the wave-specialised form could not stage.  A patch that is too large even here (wide
     // strided / dilated 2-D windows) is retried on the narrowest tile (64 positions) before giving up.
-    static const bool eight = getenv("AICG_CONV_8WAVE") ? atoi(getenv("AICG_CONV_8WAVE")) != 0 : true;
+    AICG_SWITCH(eight, "AICG_CONV_8WAVE", 1);
     auto single_role = [&]() -> int {
         if (BM == 160 && blocks(160, 128) >= want) return run_sr_160x128(p, st);
-        if (BM == 128 && blocks(128, 128) >= want) return eight ? run_sr_128x128_8w(p, st) : run_sr_128x128_4w(p, st);
+#ifdef AICG_DEV_SWITCHES
+        if (BM == 128 && blocks(128, 128) >= want && !eight) return run_sr_128x128_4w(p, st);
+#else
+        (void)eight;
+#endif
+        if (BM == 128 && blocks(128, 128) >= want) return run_sr_128x128_8w(p, st);
         if (BM == 96 && blocks(96, 128) >= want) return run_sr_96x128(p, st);
         if (M > 32) {
             if (blocks(64, 128) >= want) return run_sr_64x128(p, st);

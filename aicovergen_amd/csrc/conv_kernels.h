@@ -1175,7 +1175,7 @@ inline int choose_tile_width(const ConvArgs& p, int BN) {
     int TW = 1 << ilog2(p.Wo);
     if (TW > BN) TW = BN;
     if (p.Ho == 1) return BN;
-    static const bool square = getenv("AICG_CONV_SQUARE") ? atoi(getenv("AICG_CONV_SQUARE")) != 0 : true;
+    AICG_SWITCH(square, "AICG_CONV_SQUARE", 1);
     if (!square) return TW;
     int best = TW;
     long best_cost = -1;
@@ -1266,12 +1266,12 @@ static int launch_conv_ws(ConvArgs& p, hipStream_t stream) {
     const bool gen = p.shuffle || p.res_mul;
     p.stagger = p.stagger_first = 0;
     {
-        static const int wide = getenv("AICG_CONV_WIDE") ? atoi(getenv("AICG_CONV_WIDE")) : 1;
+        AICG_SWITCH(wide, "AICG_CONV_WIDE", 1);
         p.wide_ok = wide && (size_t)(WM * WN) * kEpiScratch * sizeof(float) <= lds ? conv_wide_ok(p) : 0;
     }
 #ifndef AICG_EMULATED
     {
-        static const int stag = getenv("AICG_CONV_STAGGER") ? atoi(getenv("AICG_CONV_STAGGER")) : 0;
+        AICG_SWITCH(stag, "AICG_CONV_STAGGER", 0);
         const long nwg = gx * idiv_up(p.Cout_g, BM) * p.groups;
         const int per_cu = (int)((160 * 1024) / lds);
         if (stag && WM * WN == 4 && per_cu == 2 && nwg >= 8L * 512) {   // >= 8 rounds: the one-off delay costs < 1/16 of the launch
@@ -1320,14 +1320,14 @@ static int launch_conv16(ConvArgs& p, hipStream_t stream) {
     const long gx = (long)p.N * p.tiles_h * p.tiles_w;
     if (gx > 2147483647L) return fail(AICG_E_SHAPE, "conv: too many output tiles");
     dim3 grid((unsigned)gx, (unsigned)idiv_up(p.Cout_g, BM), (unsigned)p.groups);
-    static const int ws = getenv("AICG_CONV_WS") ? atoi(getenv("AICG_CONV_WS")) : 1;
+    AICG_SWITCH(ws, "AICG_CONV_WS", 1);
     const bool off_ok = (long)p.BKC * p.x_sc + (long)p.H * p.x_sh < (1L << 29) && (long)p.taps * p.Cin_pad * p.Mpad < (1L << 29);
     if (ws && off_ok) {  // wave-specialised form (KSTAGE rows per stage, double-buffered)
         const int xrw = xr <= 8 ? 8 : 12;
         const size_t ldsw = (size_t)(2 * xrw * 256 + 2 * WsGeom<BM, KSTAGE>::WS_ELEMS) * sizeof(float);
         const bool gen = p.shuffle || p.res_mul;
         {
-            static const int wide = getenv("AICG_CONV_WIDE") ? atoi(getenv("AICG_CONV_WIDE")) : 1;
+            AICG_SWITCH(wide, "AICG_CONV_WIDE", 1);
             p.wide_ok = wide ? conv_wide_ok(p) : 0;
         }
         auto kern = gen ? (xrw == 8 ? conv_ws16_kernel<BM, 8, KSTAGE, true> : conv_ws16_kernel<BM, 12, KSTAGE, true>)

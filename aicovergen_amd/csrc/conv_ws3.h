@@ -352,12 +352,12 @@ static int launch_conv_ws3(ConvArgs& p, hipStream_t stream) {
     const bool gen = p.shuffle || p.res_mul;
     p.stagger = p.stagger_first = 0;
     {
-        static const int wide = getenv("AICG_CONV_WIDE") ? atoi(getenv("AICG_CONV_WIDE")) : 1;
+        AICG_SWITCH(wide, "AICG_CONV_WIDE", 1);
         p.wide_ok = wide && (size_t)(WM * WN) * kEpiScratch * sizeof(float) <= lds ? conv_wide_ok(p) : 0;
     }
 #ifndef AICG_EMULATED
     {
-        static const int stag = getenv("AICG_CONV_STAGGER") ? atoi(getenv("AICG_CONV_STAGGER")) : 0;
+        AICG_SWITCH(stag, "AICG_CONV_STAGGER", 0);
         const long nwg = gx * idiv_up(p.Cout_g, BM) * p.groups;
         const int per_cu = (int)((160 * 1024) / lds);
         if (stag && WM * WN == 4 && per_cu == 2 && nwg >= 8L * 512) {   // >= 8 rounds: the one-off delay costs < 1/16 of the launch
@@ -647,7 +647,7 @@ static int launch_conv_ws3m16h(ConvArgs& p, hipStream_t stream) {
     const bool gen = p.shuffle || p.res_mul;
     p.stagger = p.stagger_first = 0;
     {
-        static const int wide = getenv("AICG_CONV_WIDE") ? atoi(getenv("AICG_CONV_WIDE")) : 1;
+        AICG_SWITCH(wide, "AICG_CONV_WIDE", 1);
         p.wide_ok = wide && (size_t)4 * kEpi16Scratch * sizeof(float) <= lds ? conv_wide_ok(p) : 0;
     }
     auto kern = gen ? (xq == 2 ? conv_ws3m16h_kernel<BM, 2, KS, true> : conv_ws3m16h_kernel<BM, 3, KS, true>)

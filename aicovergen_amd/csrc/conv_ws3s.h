@@ -279,7 +279,7 @@ static int launch_conv_ws3s(ConvArgs& p, hipStream_t stream) {
     const bool gen = p.shuffle || p.res_mul;
     p.stagger = p.stagger_first = 0;
     {
-        static const int wide = getenv("AICG_CONV_WIDE") ? atoi(getenv("AICG_CONV_WIDE")) : 1;
+        AICG_SWITCH(wide, "AICG_CONV_WIDE", 1);
         p.wide_ok = wide && (size_t)(WM * WN) * kEpiScratch * sizeof(float) <= lds ? conv_wide_ok(p) : 0;
     }
     auto kern = gen ? (xi == 1 ? conv_ws3s_kernel<BM, BN, WM, WN, 1, KS, true>

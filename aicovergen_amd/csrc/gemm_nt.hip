@@ -367,8 +367,8 @@ static int gemm_nt_launch(bool split, const float* a, const float* w, const floa
     if (R == 0) return AICG_OK;
     GemmArgs p{a, w, bias, row_scale, row_shift, res, c, (long)R, K, O, (long)lda, (long)ldw, (long)ldc, (long)ldr,
                rows_per_ch, n_ch, act, 0, 0};
-    static const int order = getenv("AICG_GEMM_ORDER") ? atoi(getenv("AICG_GEMM_ORDER")) : 1;
-    static const int wide = getenv("AICG_GEMM_WIDE") ? atoi(getenv("AICG_GEMM_WIDE")) : 1;
+    AICG_SWITCH(order, "AICG_GEMM_ORDER", 1);
+    AICG_SWITCH(wide, "AICG_GEMM_WIDE", 1);
     p.order = order;
     auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     p.wide = wide && al(c) && (ldc & 3) == 0 && (!res || (al(res) && (ldr & 3) == 0)) && (!bias || al(bias)) && (O & 3) == 0;

@@ -374,7 +374,7 @@ extern "C" int aicg_gru_bidir_2wg(const float* gi, const float* whh_t, const flo
     (void)hipMemsetAsync(xchg_scratch, 0, xbytes + 64, (hipStream_t)stream);
     unsigned long long* xb = (unsigned long long*)xchg_scratch;
     int* err = (int*)((char*)xchg_scratch + xbytes);
-    static const int force_agent = getenv("AICG_GRU_AGENT_STORES") ? atoi(getenv("AICG_GRU_AGENT_STORES")) : 0;  // A/B switch
+    AICG_SWITCH(force_agent, "AICG_GRU_AGENT_STORES", 0);  // A/B switch
     if (hidden == 256) {
         constexpr int KR = 208;
         const size_t lds = (size_t)(256 + 384 + (256 - KR) * 384) * sizeof(float);

@@ -10,6 +10,9 @@
 // each output bin once: the kernel is HBM/LDS bound, there is no GEMM here (a 7680-point DFT as a
 // matrix product would be 600x the flops).
 #include "common.h"
+#include <cstdint>
+
+#include "fft_reg.h"
 
 namespace aicg {
 
@@ -231,6 +234,199 @@ __global__ void __launch_bounds__(256) istft_ola_kernel(const float* __restrict_
     }
 }
 
+// ---- compile-time-plan kernels (fft_reg.h): one workgroup = FR frames, three register passes ------------------------------------------
+__device__ __forceinline__ int reflect_index(int n, int L) {
+    if (n < 0) n = -n;
+    if (n >= L) n = 2 * (L - 1) - n;
+    return n;
+}
+
+template <class P>
+__global__ void __launch_bounds__(P::NT) stft_reg_kernel(StftArgs p) {
+    using namespace fftc;
+    constexpr int M = P::M, R0 = P::R0, R1 = P::R1, R2 = P::R2;
+    HIP_DYNAMIC_SHARED(float2, smem)
+    const int fl = threadIdx.x / P::TPF, j = threadIdx.x % P::TPF;
+    float2* const buf = smem + fl * P::SLOTS;
+    const long gf = (long)blockIdx.x * P::FR + fl;
+    const bool live = gf < (long)p.n_sig * p.n_frames;      // uniform over the TPF threads of a frame (whole waves)
+    const int s = live ? (int)(gf / p.n_frames) : 0, t = live ? (int)(gf - (long)s * p.n_frames) : 0;
+    // pass 0: samples straight from HBM (reflect padding + window), two real samples per complex point
+    if (live && j < P::T0) {
+        const float* xs = p.x + (long)s * p.L;
+        const float2* win = reinterpret_cast<const float2*>(p.window);
+        const int n_base = t * p.hop - M;                    // center=True: the frame starts n_fft / 2 before t * hop
+        const bool inside = n_base >= 0 && n_base + 2 * M <= p.L;
+        float2 v[R0];
+#pragma unroll
+        for (int u = 0; u < R0; ++u) {
+            const int m = j + u * P::T0;
+            const int n0 = n_base + 2 * m;
+            const float2 w = win[m];
+            const float a = xs[inside ? n0 : reflect_index(n0, p.L)], b = xs[inside ? n0 + 1 : reflect_index(n0 + 1, p.L)];
+            v[u] = make_float2(a * w.x, b * w.y);
+        }
+        Dft<R0, false>::run(v);
+#pragma unroll
+        for (int q = 0; q < R0; ++q) buf[slot(j * R0 + q)] = v[q];
+    }
+    __syncthreads();
+    float2 v1[R1];
+    if (live && j < P::T1) load_pass<R1, M, R0, false>(buf, p.tw_half, j, v1);
+    __syncthreads();
+    if (live && j < P::T1) {
+#pragma unroll
+        for (int q = 0; q < R1; ++q) buf[slot(out_pos<R1, R0>(j, q))] = v1[q];
+    }
+    __syncthreads();
+    float2 v2[R2];
+    if (live && j < P::T2) load_pass<R2, M, R0 * R1, false>(buf, p.tw_half, j, v2);
+    __syncthreads();
+    if (live && j < P::T2) {
+#pragma unroll
+        for (int q = 0; q < R2; ++q) buf[slot(j + q * (R0 * R1))] = v2[q];
+    }
+    __syncthreads();
+    if (!live) return;
+    // split step: X[k] = E[k] + W_N^k O[k],  E = (Z[k] + conj Z[M-k])/2,  O = (Z[k] - conj Z[M-k])/(2i)
+    float* const dst0 = p.out + (long)s * p.o_sig + (long)t * p.o_frame;
+    for (int k = j; k < p.n_bins; k += P::TPF) {
+        const float2 zk = buf[slot(k == M ? 0 : k)];
+        const float2 zm = cconj(buf[slot((k == 0 || k == M) ? 0 : M - k)]);
+        const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y + zm.y));
+        const float2 d = csub(zk, zm);
+        const float2 o = make_float2(0.5f * d.y, -0.5f * d.x);
+        const float2 X = cadd(e, cmul(p.tw_full[k], o));
+        float* dst = dst0 + (long)k * p.o_bin;
+        dst[0] = X.x;
+        dst[p.o_im] = X.y;
+    }
+}
+
+template <class P>
+__global__ void __launch_bounds__(P::NT) istft_frames_reg_kernel(IstftArgs p) {
+    using namespace fftc;
+    constexpr int M = P::M, N = 2 * M, R0 = P::R0, R1 = P::R1, R2 = P::R2;
+    HIP_DYNAMIC_SHARED(float2, smem)
+    const int fl = threadIdx.x / P::TPF, j = threadIdx.x % P::TPF;
+    float2* const buf = smem + fl * P::SLOTS;
+    const long gf = (long)blockIdx.x * P::FR + fl;
+    const bool live = gf < (long)p.n_sig * p.n_frames;
+    const int s = live ? (int)(gf / p.n_frames) : 0, t = live ? (int)(gf - (long)s * p.n_frames) : 0;
+    // pass 0 input = merge step from HBM: Z[k] = E[k] + i O[k], E = (X[k] + conj X[M-k])/2, O = (X[k] - conj X[M-k])/2 * conj(W_N^k)
+    if (live && j < P::T0) {
+        const float* base = p.spec + (long)s * p.i_sig + (long)t * p.i_frame;
+        float2 v[R0];
+#pragma unroll
+        for (int u = 0; u < R0; ++u) {
+            const int k = j + u * P::T0, km = M - k;
+            float2 xk = make_float2(0.f, 0.f), xm = make_float2(0.f, 0.f);
+            if (k < p.n_bins) { xk.x = base[(long)k * p.i_bin]; xk.y = base[(long)k * p.i_bin + p.i_im]; }
+            if (km < p.n_bins) { xm.x = base[(long)km * p.i_bin]; xm.y = base[(long)km * p.i_bin + p.i_im]; }
+            if (k == 0) { xk.y = 0.f; xm.y = 0.f; }  // C2R: imaginary parts of DC and Nyquist are ignored
+            xm.y = -xm.y;
+            const float2 e = make_float2(0.5f * (xk.x + xm.x), 0.5f * (xk.y + xm.y));
+            const float2 d = make_float2(0.5f * (xk.x - xm.x), 0.5f * (xk.y - xm.y));
+            const float2 o = cmul(d, cconj(p.tw_full[k]));
+            v[u] = make_float2(e.x - o.y, e.y + o.x);
+        }
+        Dft<R0, true>::run(v);
+#pragma unroll
+        for (int q = 0; q < R0; ++q) buf[slot(j * R0 + q)] = v[q];
+    }
+    __syncthreads();
+    float2 v1[R1];
+    if (live && j < P::T1) load_pass<R1, M, R0, true>(buf, p.tw_half, j, v1);
+    __syncthreads();
+    if (live && j < P::T1) {
+#pragma unroll
+        for (int q = 0; q < R1; ++q) buf[slot(out_pos<R1, R0>(j, q))] = v1[q];
+    }
+    __syncthreads();
+    if (live && j < P::T2) {
+        // last pass: result q of butterfly j is element j + q NS -- lane-contiguous: windowed, scaled, straight to HBM
+        float2 v2[R2];
+        load_pass<R2, M, R0 * R1, true>(buf, p.tw_half, j, v2);
+        const float inv = 1.0f / (float)M;
+        const float2* win = reinterpret_cast<const float2*>(p.window);
+        float2* dst = reinterpret_cast<float2*>(p.frames + gf * N);
+#pragma unroll
+        for (int q = 0; q < R2; ++q) {
+            const int m = j + q * (R0 * R1);
+            const float2 w = win[m];
+            dst[m] = make_float2(v2[q].x * inv * w.x, v2[q].y * inv * w.y);
+        }
+    }
+}
+
+// float4 form of istft_ola_kernel: four consecutive output samples share their frame set when L, hop and N / 2 are multiples of 4
+__global__ void __launch_bounds__(256) istft_ola4_kernel(const float* __restrict__ frames, const float* __restrict__ window,
+                                                         float* __restrict__ out, int n_sig, int L, int N, int hop, int n_frames) {
+    const long total4 = (long)n_sig * (L >> 2);
+    for (long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += (long)gridDim.x * blockDim.x) {
+        const int s = (int)(i4 / (L >> 2));
+        const int n = (int)(i4 - (long)s * (L >> 2)) * 4;
+        const int pidx = n + N / 2;
+        int t_hi = pidx / hop;
+        if (t_hi > n_frames - 1) t_hi = n_frames - 1;
+        int t_lo = (pidx - N + hop) / hop;
+        if (pidx - N + 1 <= 0) t_lo = 0;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), env = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* fs = frames + (long)s * n_frames * N;
+        for (int t = t_lo; t <= t_hi; ++t) {
+            const int q = pidx - t * hop;
+            const float4 w = *reinterpret_cast<const float4*>(window + q);
+            const float4 f = *reinterpret_cast<const float4*>(fs + (long)t * N + q);
+            acc.x += f.x; acc.y += f.y; acc.z += f.z; acc.w += f.w;
+            env.x += w.x * w.x; env.y += w.y * w.y; env.z += w.z * w.z; env.w += w.w * w.w;
+        }
+        *reinterpret_cast<float4*>(out + (long)s * L + n) = make_float4(acc.x / env.x, acc.y / env.y, acc.z / env.z, acc.w / env.w);
+    }
+}
+
+// the frame lengths of the reference's model table (model_data.json: mdx_n_fft_scale_set 4096 ... 16384) and RMVPE's 1024
+using Plan512 = fftc::Plan<8, 8, 8, 4>;
+using Plan2048 = fftc::Plan<16, 16, 8, 1>;
+using Plan2560 = fftc::Plan<16, 16, 10, 1>;
+using Plan3072 = fftc::Plan<16, 16, 12, 1>;
+using Plan3840 = fftc::Plan<16, 16, 15, 1>;
+using Plan4096 = fftc::Plan<16, 16, 16, 1>;
+using Plan8192 = fftc::Plan<16, 16, 32, 1>;
+
+template <class P>
+static int launch_stft_reg(const StftArgs& p, hipStream_t st) {
+    const size_t lds = (size_t)P::FR * P::SLOTS * sizeof(float2);
+    const long total = (long)p.n_sig * p.n_frames;
+    if (lds > 64 * 1024) allow_dynamic_lds((const void*)stft_reg_kernel<P>, lds);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(stft_reg_kernel<P>), dim3((unsigned)ldiv_up(total, P::FR)), dim3(P::NT), lds, st, p);
+    return check_launch("stft_reg_kernel");
+}
+
+template <class P>
+static int launch_istft_reg(const IstftArgs& p, hipStream_t st) {
+    const size_t lds = (size_t)P::FR * P::SLOTS * sizeof(float2);
+    const long total = (long)p.n_sig * p.n_frames;
+    if (lds > 64 * 1024) allow_dynamic_lds((const void*)istft_frames_reg_kernel<P>, lds);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(istft_frames_reg_kernel<P>), dim3((unsigned)ldiv_up(total, P::FR)), dim3(P::NT), lds, st, p);
+    return check_launch("istft_frames_reg_kernel");
+}
+
+// 1 = no compile-time plan for this length (the run-time-plan kernels take it)
+template <class Args, class F>
+static int with_plan(int M, const Args& p, hipStream_t st, F&& launch) {
+    (void)p; (void)st;
+    switch (M) {
+        case 512: return launch(Plan512{});
+        case 2048: return launch(Plan2048{});
+        case 2560: return launch(Plan2560{});
+        case 3072: return launch(Plan3072{});
+        case 3840: return launch(Plan3840{});
+        case 4096: return launch(Plan4096{});
+        case 8192: return launch(Plan8192{});
+        default: return 1;
+    }
+}
+
 static bool smooth235(int m) {
     if (m < 1) return false;
     for (int p : {2, 3, 5})
@@ -263,6 +459,10 @@ extern "C" int aicg_stft(const float* x, float* out, const float* window, const 
     const int M = n_fft / 2;
     StftArgs p{x, out, window, (const float2*)tw_half, (const float2*)tw_full, n_sig, L, n_fft, hop, n_frames,
                n_bins_out, pick_frames_per_block(M), (long)o_sig, (long)o_im, (long)o_bin, (long)o_frame};
+    if (((uintptr_t)window & 7) == 0) {   // the plan kernels read the window as float2
+        const int rc = with_plan(M, p, (hipStream_t)stream, [&](auto plan) { return launch_stft_reg<decltype(plan)>(p, (hipStream_t)stream); });
+        if (rc <= 0) return rc;
+    }
     const size_t lds = (size_t)2 * p.fr_per_block * M * sizeof(float2);
     const long total = (long)n_sig * n_frames;
     const unsigned grid = (unsigned)((total + p.fr_per_block - 1) / p.fr_per_block);
@@ -284,6 +484,10 @@ extern "C" int aicg_istft_frames(const float* spec, float* frames, const float* 
     const int M = n_fft / 2;
     IstftArgs p{spec, frames, window, (const float2*)tw_half, (const float2*)tw_full, n_sig, n_fft, n_frames,
                 n_bins_in, pick_frames_per_block(M), (long)i_sig, (long)i_im, (long)i_bin, (long)i_frame};
+    if (((uintptr_t)window & 7) == 0 && ((uintptr_t)frames & 7) == 0) {
+        const int rc = with_plan(M, p, (hipStream_t)stream, [&](auto plan) { return launch_istft_reg<decltype(plan)>(p, (hipStream_t)stream); });
+        if (rc <= 0) return rc;
+    }
     const size_t lds = (size_t)2 * p.fr_per_block * M * sizeof(float2);
     const long total = (long)n_sig * n_frames;
     const unsigned grid = (unsigned)((total + p.fr_per_block - 1) / p.fr_per_block);
@@ -301,6 +505,13 @@ extern "C" int aicg_istft_ola(const float* frames, const float* window, float* o
         return fail(AICG_E_SHAPE, "aicg_istft_ola: L=%d not covered by %d frames", L, n_frames);
     const long total = (long)n_sig * L;
     if (total == 0) return AICG_OK;
+    if ((L & 3) == 0 && (hop & 3) == 0 && (n_fft & 7) == 0 && ((uintptr_t)frames & 15) == 0 && ((uintptr_t)window & 15) == 0 &&
+        ((uintptr_t)out & 15) == 0) {
+        const unsigned grid4 = (unsigned)lmin((total / 4 + 255) / 256, 256L * 16);
+        hipLaunchKernelGGL(istft_ola4_kernel, dim3(grid4), dim3(256), 0, (hipStream_t)stream, frames, window, out, n_sig, L, n_fft, hop,
+                           n_frames);
+        return check_launch("istft_ola4_kernel");
+    }
     unsigned grid = (unsigned)lmin((total + 255) / 256, 256L * 8);
     hipLaunchKernelGGL(istft_ola_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, frames, window, out, n_sig, L,
                        n_fft, hop, n_frames);

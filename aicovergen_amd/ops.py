@@ -146,7 +146,7 @@ class ConvDesc(ctypes.Structure):
                 ("act_slope", ctypes.c_float), ("out_scale", ctypes.c_float), ("accumulate", ctypes.c_int32),
                 ("res_before_act", ctypes.c_int32), ("pad_h_end", ctypes.c_int32), ("pad_w_end", ctypes.c_int32),
                 ("shuffle", ctypes.c_int32), ("res_mul", ctypes.c_int32), ("packed_v3", ctypes.c_int32),
-                ("split", ctypes.c_int32), ("frozen_narrow", ctypes.c_int32)]
+                ("split", ctypes.c_int32)]
 
 
 def conv_bkc(taps):
@@ -234,8 +234,6 @@ class PackedConv:
         self.stride, self.padding, self.dilation = stride, padding, dilation
         device = weight.device if device is None else device
         self.split = bool(split_precision)
-        # packed inside fp32_layers(): an f0 model (aicg_conv_desc.frozen_narrow); AICG_FROZEN_NARROW=0: A/B switch of tools/c1_triangulate.py
-        self.frozen_narrow = bool(_fp32_depth) and os.environ.get("AICG_FROZEN_NARROW", "1") != "0"
         self.w = pack_conv_weight(weight.to(device), groups, self.split)
         self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
 
@@ -267,6 +265,20 @@ class ConvProfile:
         self.flops = 0.0
         self.bytes = 0.0  # algorithmic HBM bytes: input + packed weights + output (+ residual / accumulate reads), each once
         self.launches = 0
+        self.shapes = []  # per launch: (shape key, flops) -- by_shape() groups them
+
+    def by_shape(self):
+        """[{shape, launches, ms, tflops, gflop}] sorted by time: where the family's time goes (bench.py --conv-shapes)."""
+        torch.cuda.synchronize()
+        agg = {}
+        for (key, fl), (a, b) in zip(self.shapes, self.events):
+            r = agg.setdefault(key, [0, 0.0, 0.0])
+            r[0] += 1
+            r[1] += a.elapsed_time(b)
+            r[2] += fl
+        rows = [{"shape": k, "launches": v[0], "ms": v[1], "gflop": v[2] / 1e9, "tflops": v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0}
+                for k, v in agg.items()]
+        return sorted(rows, key=lambda r: -r["ms"])
 
     def summary(self):
         torch.cuda.synchronize()
@@ -326,7 +338,6 @@ def conv(x, pc, res=None, out=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NON
     d.shuffle, d.res_mul = int(shuffle), 1 if res_mul else 0
     d.packed_v3 = 1
     d.split = 1 if getattr(pc, "split", False) else 0
-    d.frozen_narrow = 1 if getattr(pc, "frozen_narrow", False) else 0
     prof = conv_profile
     if prof is not None and x.is_cuda:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -339,6 +350,10 @@ def conv(x, pc, res=None, out=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NON
         prof.bytes += 4.0 * (n * c * h * w + pc.cout * (pc.cin // pc.groups) * pc.kh * pc.kw
                              + n * pc.cout * ho * wo * (1 + (r4 is not None) + bool(accumulate)))
         prof.launches += 1
+        prof.shapes.append(("N%d C%d>%d %dx%d k%dx%d s%d,%d d%d,%d g%d%s%s%s" % (
+            n, c, pc.cout, h, w, pc.kh, pc.kw, pc.stride[0], pc.stride[1], pc.dilation[0], pc.dilation[1], pc.groups,
+            " res" if r4 is not None else "", " acc" if accumulate else "", " shuf" if shuffle else ""),
+            2.0 * n * pc.cout * (pc.cin // pc.groups) * pc.kh * pc.kw * ho * wo))
     return out
 
 
@@ -475,7 +490,10 @@ def rownorm_act(x, gamma, beta, act=ACT_NONE, eps=1e-5, out=None):
     if out is None:
         out = torch.empty_like(x)
     _check(x, gamma, beta, out)
-    _call("aicg_rownorm_act", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), x.shape[0], x.shape[1], float(eps), act,
+    need = ctypes.c_int64(0)
+    _call("aicg_rownorm_act_workspace_floats", x.shape[0], x.shape[1], ctypes.addressof(need))
+    ws = torch.empty(need.value, dtype=torch.float32, device=x.device) if need.value else None
+    _call("aicg_rownorm_act", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), x.shape[0], x.shape[1], float(eps), act, _ptr(ws),
               _stream(x))
     return out
 

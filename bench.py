@@ -234,6 +234,7 @@ def main():
                          "(bf16 hi + lo operands, 3 bf16 MFMAs per product, fp32 accumulation); default: $AICG_PRECISION or fp32")
     ap.add_argument("--track-seconds", type=float, default=None)
     ap.add_argument("--dump", type=str, default=None, help="write the last step's outputs (npz) for cross-checking runs")
+    ap.add_argument("--conv-shapes", type=str, default=None, help="write the instrumented step's per-layer-shape conv table (JSON)")
     args = ap.parse_args()
 
     rc = self_launch(args)
@@ -391,6 +392,9 @@ def main():
                 "algorithmic_bytes_per_launch": conv["bytes"] / max(1, conv["launches"]),
                 "kernel_ms_per_step": conv["ms"]}
             res["stages"] = stage_table(conv, sprof.summary(), 1)
+            if args.conv_shapes:
+                with open(args.conv_shapes, "w") as f:
+                    json.dump(prof.by_shape(), f, indent=0)
         else:
             res["roofline"] = None
         if world == 1 and not args.no_cpu_baseline and not emu:

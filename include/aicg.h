@@ -119,11 +119,6 @@ typedef struct aicg_conv_desc {
                                      group and more than 16 output channels are then computed as hi*hi + hi*lo + lo*hi on the
                                      bf16 matrix pipe with fp32 accumulation (csrc/conv_ws3s.h: ~1e-5 relative to the fp32
                                      kernels); the other layers run the fp32 kernels unchanged */
-    int32_t frozen_narrow;        /* nonzero: 16- / 48-row layers of this model keep the round-1 4-byte-fragment kernel instead of the
-                                     8-byte-fragment one.  Set for the f0 estimators: both kernels are equally close to the fp32
-                                     reference (~3e-7), but f0 feeds the vocoder's phase accumulator, where ANY change of summation
-                                     order moves the end-to-end waveform at the 1e-4 level -- their numerics stay as the goldens
-                                     were validated */
 } aicg_conv_desc;
 
 int aicg_conv_bkc(int taps);
@@ -168,9 +163,13 @@ int aicg_feats_prepare(const float* feats, const float* feats0, const float* pit
 int aicg_layernorm_ct(const float* x, const float* res, const float* gamma, const float* beta, float* out, int N,
                       int C, int64_t T, float eps, int64_t x_sn, int64_t r_sn, int64_t o_sn, void* stream);
 
-/* Per-row statistics over time + affine + activation: HuBERT feature extractor GroupNorm(512, 512) + GELU. */
+/* Per-row statistics over time + affine + activation: HuBERT feature extractor GroupNorm(512, 512) + GELU (fairseq
+ * ConvFeatureExtractionModel layer 0; call site src/vc_infer_pipeline.py:398-406).  `workspace`: NULL, or
+ * aicg_rownorm_act_workspace_floats(rows, T) floats of scratch -- with it, rows of >= 4096 elements take the split form (partial
+ * moments per row segment, then one float4 normalise + activate stream); without it one workgroup per row. */
+int aicg_rownorm_act_workspace_floats(int rows, int64_t T, int64_t* n_floats);
 int aicg_rownorm_act(const float* x, const float* gamma, const float* beta, float* out, int rows, int64_t T,
-                     float eps, int act, void* stream);
+                     float eps, int act, float* workspace, void* stream);
 
 /* Fused softmax attention over channel-major q/k/v (H*D, T): o = softmax(scale * q^T k + relk) v.
  * relk (H, 2*window+1, T) holds q_i . E^k_m (attentions.py:238-243) or is NULL (HuBERT).  lse (H, T) receives the

@@ -23,7 +23,7 @@ def build_emu(force=False):
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h")) + \
         glob.glob(os.path.join(HERE, "include", "hip", "*.h"))
     flags = ["-x", "c++", "-std=c++17", "-O2", "-g", "-fPIC", "-I", os.path.join(HERE, "include"),
-             "-Wno-unused-value", "-Wno-unknown-attributes", "-ffp-contract=fast-honor-pragmas", "-mfma"]  # hipcc's default contraction mode for device code
+             "-Wno-unused-value", "-Wno-unknown-attributes", "-DAICG_DEV_SWITCHES", "-ffp-contract=fast-honor-pragmas", "-mfma"]  # hipcc's default contraction mode for device code
     jobs, objs = [], []
     newest_hdr = max(os.path.getmtime(h) for h in hdrs)
     for s in srcs:

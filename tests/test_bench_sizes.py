@@ -65,11 +65,21 @@ def test_c1_pipeline_vs_reference_golden():
     rel = np.sqrt(np.sum(diff.astype(np.float64) ** 2) / np.sum(ref.astype(np.float64) ** 2))
     print("C1 vs reference: rel rms %.3e, max |diff| %d of peak %d, <= 1 LSB on %.4f, exact on %.4f"
           % (rel, diff.max(), np.abs(ref).max(), (diff <= 1).mean(), (diff == 0).mean()))
-    # fp32 kernels vs the reference's fp32 CPU run through ~150 layers: the waveform bar is relative RMS <= 1e-3;
-    # the truncating int16 cast at a peak of ~27 000 turns that into a few LSB, so the <= 1 LSB rate is reported and only
-    # loosely gated (measured r2: rel 1.16e-4, <= 1 LSB on 93 %, max 9 LSB)
-    assert rel < 1e-3
-    assert diff.max() <= 1e-3 * np.abs(ref).max() and (diff <= 1).mean() > 0.6
+    # Tolerance, triangulated (tests/golden/make_fp64_c1.py): the same pipeline evaluated in float64 stands in for exact arithmetic.
+    # The REFERENCE's own fp32 output is 1.20e-4 relative RMS / 10 LSB / <= 1 LSB on 92.6 % away from it, its f0 2.3e-7 -- that is
+    # the noise floor of ANY fp32 evaluation (the vocoder's source integrates f0 over the whole 36 s chunk, so the waveform reacts
+    # to every reordering of the f0 path's sums: two equally accurate kernel choices measured 2.5e-4 and 4.5e-4 from float64).
+    # Gates: SURVEY 8d's relative RMS <= 1e-3 (= 8x the reference's own distance from float64: three fp32 evaluations sampled
+    # 1.2e-4, 2.5e-4 and 4.5e-4) against the reference AND against float64; largest deviation within 4x the reference's; f0 as close
+    # to float64 as the reference's is (2x), all coarse bins equal (below).
+    g64 = np.load(os.path.join(GOLD, "pipeline_c1_30s_fp64.npz"))
+    dec = int(g64["decim"][0])
+    d64 = np.abs(out[::dec].astype(np.int32) - g64["audio"].astype(np.int32))
+    rel64 = np.sqrt(np.sum(d64.astype(np.float64) ** 2) / np.sum(g64["audio"].astype(np.float64) ** 2))
+    print("C1 vs float64: rel rms %.3e, max |diff| %d, <= 1 LSB on %.4f   (reference vs float64: %.3e, %d, %.4f)"
+          % (rel64, d64.max(), (d64 <= 1).mean(), float(g64["ref_rel_rms"][0]), int(g64["ref_max_lsb"][0]), float(g64["ref_le1"][0])))
+    assert rel < 1e-3 and rel64 < 1e-3
+    assert d64.max() <= 4 * int(g64["ref_max_lsb"][0]) and diff.max() <= 2e-3 * np.abs(ref).max()
     # f0 bins against the reference's own get_f0 output
     _, audio_pad, opt_ts, p_len = vc.plan(audio)
     assert opt_ts == []                                             # 30 s < x_max: a single chunk
@@ -89,27 +99,34 @@ def test_c1_pipeline_vs_reference_golden():
     voiced = (f0[:n] > 0) & (gold["f0"][:n] > 0)
     assert np.array_equal(f0[:n] > 0, gold["f0"][:n] > 0) or (np.sum((f0[:n] > 0) != (gold["f0"][:n] > 0)) <= 0.002 * n)
     assert np.max(np.abs(f0[:n][voiced] / gold["f0"][:n][voiced] - 1)) < 1e-3
+    v64 = (f0[:n] > 0) & (g64["f0"][:n] > 0)
+    e64 = np.sqrt(np.mean((f0[:n][v64] / g64["f0"][:n][v64] - 1) ** 2))
+    print("C1 f0 vs float64: relative rms %.3e (reference vs float64: %.3e)" % (e64, float(g64["ref_f0_rel_rms"][0])))
+    assert e64 <= 2.0 * float(g64["ref_f0_rel_rms"][0])
+    assert np.array_equal(coarse[:n], g64["coarse"][:n])
 
 
-def test_66s_chunk_hubert_and_synth_vs_oracle():
-    """The chunk size of the (3,10,60,65) preset: 1 056 160 samples -> T_h = 3300 (4-way split attention, 64x64 tiles on the
-    QKV/FFN GEMMs), synthesizer T = 6600 -> 2 640 000 output samples (vocoder tiles of the bench)."""
+@pytest.mark.parametrize("n", [1056160, 640160])
+def test_chunk_hubert_and_synth_vs_oracle(n):
+    """The chunk sizes of the two presets: (3,10,60,65) -> 1 056 160 samples, T_h = 3300 (4-way split attention, 64x64
+    tiles on the QKV/FFN GEMMs), synthesizer T = 6600 -> 2 640 000 output samples (vocoder tiles of the bench); (1,6,38,41) ->
+    640 160 samples, T_h = 2000, T = 4000 -> 1 600 000 samples (other tile / attention-split choices)."""
     from aicovergen_amd.hubert import HubertModel
     from aicovergen_amd.infer_pack.models import SynthesizerTrnMs768NSFsid
-    n = 1056160
+    th = (n - 400) // 320 + 1
     wav = torch.from_numpy(vocal_like(n / 16000.0 + 0.01, 16000, seed=31)[:n]).unsqueeze(0)
     cfg = weights.HUBERT_BASE
     sd = weights.hubert_state_dict(cfg, 1234)
     m = HubertModel(sd, cfg).to("cuda:0")
     y, _ = m.extract_features(source=wav, padding_mask=None, output_layer=12)
-    assert y.shape == (1, 3300, 768)
+    assert y.shape == (1, th, 768)
     with torch.no_grad():
         ref = ohub.extract_features(sd, cfg, wav, 12)
     e = rel_rms(y, ref)
-    print("HuBERT-base T_h=3300: rel rms %.3e" % e)
+    print("HuBERT-base T_h=%d: rel rms %.3e" % (th, e))
     assert e < 1e-4
     del m, y, ref
-    scfg, T = weights.SYNTH_CFG_40K_V2, 6600
+    scfg, T = weights.SYNTH_CFG_40K_V2, 2 * th
     ssd = weights.synth_state_dict(scfg, 1236)
     net = SynthesizerTrnMs768NSFsid(*scfg, is_half=False)
     del net.enc_q
@@ -117,11 +134,11 @@ def test_66s_chunk_hubert_and_synth_vs_oracle():
     net.eval().to("cuda:0")
     phone, pitch, f0, nz, ns = synth_inputs(scfg, T, 77)
     o, _, (z, z_p, m_p, logs_p) = net.infer(phone, torch.tensor([T]), pitch, f0, torch.tensor([3]), noise_z=nz, noise_src=ns)
-    assert o.shape == (1, 1, 2640000)
+    assert o.shape == (1, 1, T * 400)
     with torch.no_grad():
         ro, (rz, rzp, rmp, rlp) = osynth.synth_infer(ssd, scfg, phone, pitch, f0, torch.tensor([3]), nz, ns)
     e_mp, e_z, e_o = rel_rms(m_p, rmp), rel_rms(z, rz), rel_rms(o, ro)
-    print("synthesizer T=6600: rel rms m_p %.3e, z %.3e, audio %.3e" % (e_mp, e_z, e_o))
+    print("synthesizer T=%d: rel rms m_p %.3e, z %.3e, audio %.3e" % (T, e_mp, e_z, e_o))
     assert e_mp < 1e-4 and e_z < 1e-4 and e_o < 1e-3
 
 

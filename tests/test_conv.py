@@ -274,16 +274,6 @@ for (ci, co, h, w, k) in [(16, 16, 1, 70000, 3), (32, 48, 6, 11000, 1), (40, 40,
     y = ops.conv(x, pc, act=ops.ACT_RELU, res=r)
     e = rel(y, F.relu(F.conv2d(x, wt, b, padding=pad)) + r)
     assert e < 1e-5, (ci, co, h, w, k, e)
-# layers packed under ops.fp32_layers() (the f0 models) keep the 4-byte-fragment kernel: same accuracy, another summation order
-x = torch.randn(1, 16, 1, 70000)
-wt = torch.randn(16, 16, 1, 3) * 0.1
-ref = F.conv2d(x, wt, None, padding=(0, 1))
-y_new = ops.conv(x, ops.PackedConv(wt, None, padding=(0, 1)))
-with ops.fp32_layers():
-    pc_frozen = ops.PackedConv(wt, None, padding=(0, 1))
-y_old = ops.conv(x, pc_frozen)
-assert pc_frozen.frozen_narrow and rel(y_new, ref) < 1e-6 and rel(y_old, ref) < 1e-6
-assert not torch.equal(y_new, y_old)
 print("m16 half-quad kernels ok")
 '''
     _run_child(code, {"AICG_CONV_M16H": "1"}, "m16 half-quad kernels ok")

@@ -81,13 +81,18 @@ def test_split_is_not_plain_bf16(dev, split):
     assert rel_rms(y, ref) < TOL
 
 
-def test_f0_models_freeze_their_narrow_kernels():
-    """Layers packed inside ops.fp32_layers() (RMVPE, CREPE, retrieval) carry aicg_conv_desc.frozen_narrow."""
+def test_fp32_layers_are_never_packed_in_split_precision():
+    """Layers packed inside ops.fp32_layers() (RMVPE, CREPE, retrieval: they select indices) stay fp32 whatever the global setting."""
     w = torch.randn(16, 16, 3)
-    assert not ops.PackedConv(w, None).frozen_narrow
-    with ops.fp32_layers():
-        assert ops.PackedConv(w, None).frozen_narrow
-    assert not ops.PackedConv(w, None).frozen_narrow
+    old = ops.split_precision
+    ops.split_precision = True
+    try:
+        assert ops.PackedConv(w, None).split
+        with ops.fp32_layers():
+            assert not ops.PackedConv(w, None).split
+        assert ops.PackedConv(w, None).split
+    finally:
+        ops.split_precision = old
 
 
 def test_default_is_fp32():

@@ -40,12 +40,14 @@ def test_conv_transpose2d(dev):
     assert rel_rms(ops.conv_transpose(dev.t(x), pt), F.conv_transpose2d(x, w, b, stride=2)) < 1e-5
 
 
-@pytest.mark.parametrize("C,with_res", [(192, True), (768, True), (1000, False), (1100, True)])
-def test_layernorm_ct(dev, C, with_res):
-    """Channel LayerNorm of (N, C, T): the register-resident kernel (C <= 256 / 768 / 1024) and the strided fallback (C = 1100),
-    ragged T (not a multiple of the 32-column tile)."""
+@pytest.mark.parametrize("C,with_res,T", [(192, True, 131), (768, True, 131), (1000, False, 131), (1100, True, 131),
+                                          (192, False, 8219), (768, True, 8219), (1000, True, 8219)])
+def test_layernorm_ct(dev, C, with_res, T):
+    """Channel LayerNorm of (N, C, T): the register-resident kernel (C <= 256 / 768 / 1024) in its 8-column form (short maps: fewer
+    than 512 workgroups of 32 columns) and its 32-column form (T = 8219), and the strided fallback (C = 1100); ragged T."""
     torch.manual_seed(3)
-    T = 3001 if dev.big else 131
+    if dev.big and T < 1000:
+        T = 3001
     x, r = torch.randn(2, C, T) + 0.3, torch.randn(2, C, T)
     g, b = torch.rand(C) + 0.5, torch.randn(C)
     y = ops.layernorm_ct(dev.t(x), dev.t(g), dev.t(b), res=dev.t(r) if with_res else None)
@@ -53,14 +55,23 @@ def test_layernorm_ct(dev, C, with_res):
     assert rel_rms(y, ref) < 1e-5
 
 
-def test_rownorm_gelu(dev):
-    """HuBERT feature extractor layer 0: GroupNorm(512, 512) over time + GELU."""
+@pytest.mark.parametrize("T", [1000, 4099, 16384 + 1, 40001])
+def test_rownorm_gelu(dev, T):
+    """HuBERT feature extractor layer 0: GroupNorm(512, 512) over time + GELU.  Rows of >= 4096 elements take the split form
+    (partial moments per 16 384-element segment, merged; float4 body with <= 3 head / tail scalars: odd T moves every row's
+    alignment); 1000: the one-workgroup-per-row form; a large mean against a small spread checks the moment merge."""
     torch.manual_seed(4)
-    T = 50000 if dev.big else 1000
+    if dev.big:
+        T = T * 5 + (T & 1)
     x = torch.randn(7, T) * 3 + 1
+    x[3] = torch.randn(T) * 0.5 + 8.0
     g, b = torch.rand(7) + 0.5, torch.randn(7)
     y = ops.rownorm_act(dev.t(x), dev.t(g), dev.t(b), act=ops.ACT_GELU)
-    assert rel_rms(y, F.gelu(F.group_norm(x.unsqueeze(0), 7, g, b, 1e-5))[0]) < 1e-5
+    ref = F.gelu(F.group_norm(x.double().unsqueeze(0), 7, g.double(), b.double(), 1e-5))[0]
+    assert rel_rms(y, ref) < 5e-6
+    y0 = ops.rownorm_act(dev.t(x), dev.t(g), dev.t(b), act=ops.ACT_NONE)
+    assert rel_rms(y0, F.group_norm(x.double().unsqueeze(0), 7, g.double(), b.double(), 1e-5)[0]) < 5e-6
+    assert rel_rms(ops.rownorm_act(dev.t(x), dev.t(g), dev.t(b), act=ops.ACT_RELU), F.relu(F.group_norm(x.unsqueeze(0), 7, g, b, 1e-5))[0]) < 1e-5
 
 
 def test_gate_and_prior(dev):

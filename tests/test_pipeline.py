@@ -78,8 +78,22 @@ def test_pipeline_small_vs_reference_golden(dev):
     _, audio_pad, opt_ts, p_len = vc.plan(audio)
     assert [int(t) for t in opt_ts] == [int(t) for t in info["opt_ts"]]     # cut points: bit-exact
     coarse, f0 = vc.get_f0("x.wav", audio_pad, p_len, 0, "rmvpe", 3, 128)
-    agree = (coarse[:p_len] == info["coarse"][:p_len]).mean()
-    assert agree > 0.98, "coarse pitch agreement %.4f" % agree
+    assert_bins_agree(coarse[:p_len], f0[:p_len], info["coarse"][:p_len], info["f0"][:p_len], info["hidden"])
+
+
+def assert_bins_agree(coarse, f0, want_coarse, want_f0, want_salience, max_rate=0.002):
+    """The C1 test's criterion: coarse-pitch bins equal to the oracle's on >= 99.8 % of the frames; every other frame
+    is listed with its f0 distance and the oracle's top-1 - top-2 salience margin and must be a neighbouring bin (a cents value
+    that rounds across a bin edge) or a near-tie of the salience argmax."""
+    n = min(len(coarse), len(want_coarse))
+    bad = np.nonzero(np.asarray(coarse[:n]) != np.asarray(want_coarse[:n]))[0]
+    top2 = np.sort(np.asarray(want_salience)[bad], axis=1)[:, -2:] if len(bad) else np.zeros((0, 2))
+    for t, m in zip(bad, top2[:, 1] - top2[:, 0]):
+        print("  frame %d: bin %d vs %d, f0 %.4f vs %.4f Hz, salience top1-top2 %.3e" % (t, coarse[t], want_coarse[t], f0[t], want_f0[t], m))
+    print("coarse-bin agreement %.5f (%d of %d frames differ)" % (1 - len(bad) / max(n, 1), len(bad), n))
+    assert len(bad) <= max_rate * n, "%d of %d coarse bins differ" % (len(bad), n)
+    for t, m in zip(bad, top2[:, 1] - top2[:, 0]):
+        assert abs(int(coarse[t]) - int(want_coarse[t])) <= 1 or m < 1e-3
 
 
 def test_change_rms_matches_oracle():
@@ -121,6 +135,10 @@ def test_pipeline_full_models_vs_oracle():
     assert rel < 1e-3
     assert diff.max() <= max(3, 1e-3 * scale), "max diff %d of peak %d" % (diff.max(), scale)
     assert (diff <= 1).mean() > 0.85
+    _, audio_pad, opt_ts, p_len = vc.plan(audio)
+    assert [int(t) for t in opt_ts] == [int(t) for t in info["opt_ts"]]     # cut points: bit-exact
+    coarse, f0 = vc.get_f0("x.wav", audio_pad, p_len, 0, "rmvpe", 3, 128)
+    assert_bins_agree(coarse[:p_len], f0[:p_len], info["coarse"][:p_len], info["f0"][:p_len], info["hidden"])
 
 
 def test_device_post_processing_matches_oracle(dev):

@@ -33,7 +33,7 @@ def test_c1_pipeline_split_vs_reference_golden():
 
 def test_66s_chunk_split_vs_oracle():
     import test_bench_sizes as t
-    t.test_66s_chunk_hubert_and_synth_vs_oracle()
+    t.test_chunk_hubert_and_synth_vs_oracle(1056160)
 
 
 def test_mdx_window_split_vs_oracle():

@@ -7,10 +7,16 @@ from aicovergen_amd import ops
 from conftest import rel_rms
 
 CASES = [  # n_fft, hop, L, n_bins_out
-    (7680, 1024, 1024 * 15, 3072),   # Voc_FT-class MDX parameters (model_data.json), short signal
-    (6144, 1024, 1024 * 12, 2048),
-    (1024, 160, 16000, 513),         # RMVPE mel front end (src/rmvpe.py:343-345)
-    (60, 16, 400, 31),               # radix 4*3*5 plan
+    (7680, 1024, 1024 * 15, 3072),   # Voc_FT-class MDX parameters (model_data.json), short signal: plan 16 x 16 x 15
+    (6144, 1024, 1024 * 12, 2048),   # plan 16 x 16 x 12
+    (5120, 1024, 1024 * 7, 2048),    # plan 16 x 16 x 10 (radix 5 inside the registers)
+    (4096, 1024, 1024 * 6 + 3, 2049),   # plan 16 x 16 x 8; odd L: the scalar overlap-add
+    (8192, 1024, 1024 * 9, 3072),    # plan 16 x 16 x 16
+    (16384, 1024, 1024 * 17, 4096),  # plan 16 x 16 x 32 (512-thread workgroups)
+    (1024, 160, 16000, 513),         # RMVPE mel front end (src/rmvpe.py:343-345): plan 8 x 8 x 8, four frames per workgroup
+    (1024, 160, 160 * 5 + 1, 513),   # ... with a ragged last workgroup (6 frames x 2 signals = 12 frames in groups of 4)
+    (60, 16, 400, 31),               # no compile-time plan: run-time radix 4 * 3 * 5
+    (2000, 250, 3000, 600),          # ... 4 * 2 * 5 * 5 * 5
 ]
 
 
@@ -40,7 +46,7 @@ def test_istft_matches_torch(dev, n_fft, hop, L, nb):
     out = ops.istft(dev.t(sp), n_fft, hop, L)
     pad = torch.zeros(2, 2, n_fft // 2 + 1 - nb, sp.shape[-1])
     c = torch.view_as_complex(torch.cat([sp, pad], 2).permute(0, 2, 3, 1).contiguous())
-    ref = torch.istft(c, n_fft=n_fft, hop_length=hop, window=torch.hann_window(n_fft), center=True)
+    ref = torch.istft(c, n_fft=n_fft, hop_length=hop, window=torch.hann_window(n_fft), center=True, length=L)
     assert out.shape[1] == L and ref.shape[1] == L
     assert rel_rms(out, ref) < 1e-5
 
