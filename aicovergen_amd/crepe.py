@@ -2,10 +2,18 @@
 f0_method='mangio-crepe' / 'mangio-crepe-tiny' (reference src/vc_infer_pipeline.py:96-137, 314-321):
 torchcrepe.predict(audio, 16000, hop, 50, 1100, model, batch_size=2*hop, pad=True) -> NaN gating -> np.interp to p_len.
 
-Frames are normalised by a reduction kernel, the six k x 1 convolutions run through the implicit-GEMM MFMA kernel
+Frames are normalised by a reduction kernel, the first three k x 1 convolutions run through the implicit-GEMM MFMA kernel
 (the k=512 / stride-4 first layer as a 4-phase k=128 convolution), BatchNorm (applied after the ReLU in CREPE) is fused
-with the 2:1 max-pool, the classifier is a k=4 convolution with a sigmoid epilogue, and the per-batch softmax + Viterbi
-decode (360 states, float64, first-index argmax like numpy) runs one workgroup per 2*hop-frame batch."""
+with the 2:1 max-pool, and the per-batch softmax + Viterbi decode (360 states, float64, first-index argmax like numpy) runs
+one workgroup per 2*hop-frame batch.
+
+The last three convolutions see 32 / 16 / 8 input positions per frame under a 64-tap "same"-padded kernel: 50 ... 87 % of every
+output's taps multiply padding zeros, and a convolution tile (128 positions of ONE frame) would be 75 ... 94 % empty (measured r3:
+9 TFLOP/s on the 256 -> 512 layer, 457 ms of a 2.25 s C4 step).  They are contracted only over the real inputs instead:
+out[n][(co, wo)] = sum_{ci, wi} Wt[(co, wo)][(ci, wi)] x[n][(ci, wi)] with the Toeplitz-expanded weight
+Wt[(co, wo)][(ci, wi)] = w[co][ci][wi - wo + 31] (zero outside the kernel), one NT GEMM per layer over the frames of a batch
+(aicg_gemm_nt: both operands contiguous along the contraction; bias + ReLU in its epilogue).  Same products, the exact zeros of
+the padding skipped; the classifier (a k = 4 kernel on 4 positions, i.e. already dense) takes the same GEMM with a sigmoid."""
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -29,6 +37,7 @@ class Crepe:
         dev = torch.device(device)
         self.device = dev
         self.layers = []
+        width = 128                                             # input positions per frame of conv2 (1024 / 4 / 2)
         for i in range(6):
             n = "conv%d" % (i + 1)
             w = sd[n + ".weight"].float()[..., 0]             # (Cout, Cin, k)
@@ -39,13 +48,18 @@ class Crepe:
                 co, _, k = w.shape                              # Conv(1 -> C, k = 512, stride 4) as 4 phases x k = 128
                 w4 = w.view(co, k // 4, 4).permute(0, 2, 1).contiguous()
                 pc = ops.PackedConv(w4, b, device=dev)
+            elif 2 * width <= w.shape[-1]:                      # at least half of every output's taps fall on the padding
+                pc = _ToeplitzGemm(w, b, width, 31, dev)
+                width //= 2
             else:
                 pc = ops.PackedConv(w, b, padding=31, padding_end=32, device=dev)
+                width //= 2
             self.layers.append((pc, s.contiguous().to(dev), t.contiguous().to(dev)))
         wf = sd["classifier.weight"].float()                    # (360, 4*C): feature index = h*C + c
         c_last = wf.shape[1] // 4
-        self.fc = ops.PackedConv(wf.view(PITCH_BINS, 4, c_last).permute(0, 2, 1).contiguous(), sd["classifier.bias"].float(),
-                                 device=dev)
+        # x reaches the classifier as (B, C, 4): feature (c, h) at c * 4 + h
+        self.fc_w = wf.view(PITCH_BINS, 4, c_last).permute(0, 2, 1).reshape(PITCH_BINS, 4 * c_last).contiguous().to(dev)
+        self.fc_b = sd["classifier.bias"].float().contiguous().to(dev)
 
     def __call__(self, frames):
         """frames (B, 1024) normalised -> (B, 360) sigmoid posteriors."""
@@ -53,9 +67,30 @@ class Crepe:
         xp = F.pad(frames, (254, 254))                                      # zero padding of the first conv
         x = xp.view(b, 383, 4).transpose(1, 2).contiguous()                 # 4-phase view X[ph][q] = xpad[4q + ph]
         for i, (pc, s, t) in enumerate(self.layers):
-            x = ops.conv(x, pc, act=ops.ACT_RELU)
+            x = pc(x) if isinstance(pc, _ToeplitzGemm) else ops.conv(x, pc, act=ops.ACT_RELU)
             x = ops.affine_maxpool2(x, s, t)
-        return ops.conv(x, self.fc, act=ops.ACT_SIGMOID)[:, :, 0]
+        return ops.dense_nt(x.view(b, -1), self.fc_w, self.fc_b, act=ops.ACT_SIGMOID)
+
+
+class _ToeplitzGemm:
+    """relu(conv1d(x, w, b)) of a (B, Cin, W) batch with `pad_left` zeros before and k - 1 - pad_left after each frame (output
+    width W), for W <= k / 2, as ONE NT GEMM over the real inputs only (module docstring)."""
+
+    def __init__(self, w, b, width, pad_left, dev):
+        co, ci, k = w.shape
+        wi = torch.arange(width).view(1, width)
+        wo = torch.arange(width).view(width, 1)
+        tap = wi - wo + pad_left                                            # (wo, wi): out[wo] += w[tap] * x[wi]
+        ok = (tap >= 0) & (tap < k)
+        wt = w[:, :, tap.clamp(0, k - 1)] * ok.to(w.dtype)                  # (co, ci, wo, wi)
+        self.w = wt.permute(0, 2, 1, 3).reshape(co * width, ci * width).contiguous().to(dev)
+        self.b = b.repeat_interleave(width).contiguous().to(dev)
+        self.cout, self.width = co, width
+
+    def __call__(self, x):
+        b = x.shape[0]
+        assert x.is_contiguous() and x.shape[2] == self.width
+        return ops.dense_nt(x.view(b, -1), self.w, self.b, act=ops.ACT_RELU).view(b, self.cout, self.width)
 
 
 def load_crepe(model, device):

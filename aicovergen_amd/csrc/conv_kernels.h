@@ -672,6 +672,48 @@ __device__ __forceinline__ void ws_epilogue32(const ConvArgs& p, f32x16 (&acc)[T
     auto epilogue = [&](auto full_tag, auto act_tag) {
         constexpr bool FULL = decltype(full_tag)::value;
         constexpr int ACT = decltype(act_tag)::value;
+        if constexpr (GEN && FULL) {
+            if (p.wide_ok == 2) {
+                // kernel = stride = 2 ConvTranspose2d scatter (shuffle == 2), interior tile, 16-byte-aligned rows.  The four registers
+                // 4 q .. 4 q + 3 of a tile are the taps (dy, dx) of ONE output channel at this lane's position: rows 2 ho + dy,
+                // columns 2 wo + dx.  Lanes (wo, wo + 1) trade halves -- the even lane keeps row dy = 0, the odd one row dy = 1 -- so
+                // that each stores FOUR consecutive outputs: one float4 store (+ one float4 skip load) per channel and lane instead of
+                // four scattered dwords (+ four loads); a wave writes 16 x 512 B runs (r3: these layers ran at 46-60 TFLOP/s, twice
+                // their HBM time, bound by the number of memory instructions).
+                const int odd = l31 & 1;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int nl = nl0 + j * 32 + l31;
+                    const int ho = h0 + (nl >> p.TWlog2), woe = w0 + (nl & (p.TW - 1)) - odd;
+                    const long y_pos = y_base + (long)(2 * ho + odd) * p.y_sh + 2 * woe;
+                    const long r_pos = r_base + (long)(2 * ho + odd) * p.r_sh + 2 * woe;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {
+                        const int c0 = (g * p.Cout_g + m_wave0 + i * 32 + 4 * half) >> 2;   // output channel of registers 0 .. 3
+                        float4 rv[4];
+                        if (p.res) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) rv[q] = *reinterpret_cast<const float4*>(p.res + r_pos + (long)(c0 + 2 * q) * p.r_sc);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float a0 = acc[i][j][4 * q], a1 = acc[i][j][4 * q + 1], a2 = acc[i][j][4 * q + 2], a3 = acc[i][j][4 * q + 3];
+                            const float g0 = __shfl_xor(odd ? a0 : a2, 1, 64), g1 = __shfl_xor(odd ? a1 : a3, 1, 64);
+                            float e[4] = {odd ? g0 : a0, odd ? g1 : a1, odd ? a2 : g0, odd ? a3 : g1};
+                            const float rr[4] = {p.res ? rv[q].x : 0.f, p.res ? rv[q].y : 0.f, p.res ? rv[q].z : 0.f, p.res ? rv[q].w : 0.f};
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                float v = act_static<ACT>(e[t], p.act, p.act_slope);
+                                v = p.res_mul ? v * rr[t] : v + rr[t];
+                                e[t] = v * p.out_scale;
+                            }
+                            *reinterpret_cast<float4*>(p.y + y_pos + (long)(c0 + 2 * q) * p.y_sc) = make_float4(e[0], e[1], e[2], e[3]);
+                        }
+                    }
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int nl = nl0 + j * 32 + l31;
@@ -791,6 +833,9 @@ __device__ __forceinline__ void ws_epilogue32_wide(const ConvArgs& p, f32x16 (&a
 inline int conv_wide_ok(const ConvArgs& p) {
     auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     auto m4 = [](long v) { return (v & 3) == 0; };
+    if (p.shuffle == 2 && !p.accumulate && !p.res_first && (p.TW & 1) == 0 && (p.Cout_g & 3) == 0 && (!p.res_mul || p.res) && al(p.y) &&
+        m4(p.y_sn) && m4(p.y_sc) && m4(p.y_sh) && (!p.res || (al(p.res) && m4(p.r_sn) && m4(p.r_sc) && m4(p.r_sh))))
+        return 2;   // the paired-lane float4 scatter of ws_epilogue32<.., GEN = true>
     if (p.shuffle || p.res_mul || (p.TW & 3)) return 0;
     if (!al(p.y) || !m4(p.y_sn) || !m4(p.y_sc) || !m4(p.y_sh)) return 0;
     if (p.res && (!al(p.res) || !m4(p.r_sn) || !m4(p.r_sc) || !m4(p.r_sh))) return 0;

@@ -247,6 +247,128 @@ __global__ void __launch_bounds__(3 * HD / 2) gru2_kernel(const float* __restric
     }
 }
 
+// ---- four-workgroup GRU (round 3): the exchange, not the dot product, bounds a step --------------------------------------------------
+// r2 measured 2.9 us per step for the two-workgroup form: ~0.5 us of FMAs, ~1 us for the partner hand-over through L2, ~0.3 us for
+// a volatile error-flag load on the critical path of every step, the rest barriers and gate math.  Here a direction is split over
+// FOUR workgroups (HD / 4 units each): the 3 HD / 4 gate rows of a workgroup are held ENTIRELY in registers (two threads per row, HD / 2
+// columns = 128 registers each, no LDS-resident weights), a step's dot product is half as long, the three partners' quarters arrive
+// concurrently (one poll round, three waves), and the error flag is looked at every 32nd step.  Same tagged-granule protocol,
+// same bounded spins, same XCD test for the plain-store fast path.  Working blocks: hardware launches 32 and uses b with
+// (b & 7) < 2 -- direction b & 7, part b >> 3: the four parts of a direction are b, b + 8, b + 16, b + 24, observed on one XCD; the
+// emulator launches 8 (direction b >> 2, part b & 3) so that a quad is contiguous in its dispatch order.
+template <int HD>
+__global__ void __launch_bounds__(3 * HD / 2) gru4_kernel(const float* __restrict__ gi, const float* __restrict__ whh_t,
+                                                          const float* __restrict__ bhh, float* __restrict__ out, long T,
+                                                          unsigned long long* xbuf, int* err, int force_agent) {
+    constexpr int HQ = HD / 4;      // units per workgroup
+    constexpr int NR = 3 * HQ;      // gate rows per workgroup
+    constexpr int NT = 2 * NR;      // threads: two per row
+    constexpr int KH = HD / 2;      // columns per thread
+    static_assert(HQ % 64 == 0 && HQ + 3 * HQ <= NT, "publishers = wave 0 .. HQ / 64 - 1, pollers = the following 3 HQ threads");
+    __shared__ __attribute__((aligned(16))) float h[HD];
+    __shared__ float gh[NT];
+    __shared__ int same_xcd_s;
+#ifdef AICG_EMULATED
+    if (blockIdx.x >= 8) return;
+    const int dir = blockIdx.x >> 2, part = blockIdx.x & 3;
+#else
+    if ((blockIdx.x & 7) >= 2) return;
+    const int dir = blockIdx.x & 7, part = blockIdx.x >> 3;
+#endif
+    const int t_ = threadIdx.x;
+    if (t_ == 0) {
+        int* xcc = err + 4;  // 8 ints inside the zeroed 64-byte tail of the scratch buffer
+        const int me = (int)(__builtin_amdgcn_s_getreg(6164) & 0xF) + 1;  // HW_REG_XCC_ID (id 20), bits [3:0]
+        __hip_atomic_store(xcc + dir * 4 + part, me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool same = true;
+        for (int q = 0; q < 4; ++q) {
+            int other = 0, spins = 0;
+            while ((other = __hip_atomic_load(xcc + dir * 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+                if (++spins > (1 << 22)) { *err = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            same = same && other == me;
+        }
+        same_xcd_s = same && !force_agent;
+    }
+    __syncthreads();
+    const bool same_xcd = same_xcd_s != 0;
+    const int rl = t_ % NR, kh = t_ / NR;               // row of this workgroup, column half
+    const int gate = rl / HQ, u = rl - gate * HQ;
+    const int row = gate * HD + part * HQ + u;          // row of W_hh (3*HD x HD), [r ; z ; n]
+    const float* W = whh_t + (long)dir * HD * 3 * HD;   // k-major: W[k * 3*HD + row]
+    const float brow = kh == 0 ? bhh[dir * 3 * HD + row] : 0.f;
+    const float* gid = gi + (long)dir * 3 * HD * T;
+    float* od = out + (long)dir * HD * T;
+    unsigned long long* mine = xbuf + ((long)(dir * 4 + part) * 2) * HQ;        // [parity][HQ]
+    float wr[KH];
+#pragma unroll
+    for (int kb = 0; kb < KH; kb += 16) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) wr[kb + q] = W[(long)(kh * KH + kb + q) * 3 * HD + row];
+        asm volatile("" ::: "memory");  // 16 loads (and their 64-bit addresses) in flight at a time, not KH
+    }
+    if (t_ < HD) h[t_] = 0.f;
+    __syncthreads();
+    const int my_unit = part * HQ + u;                  // valid for t_ < HQ (gate 0, column half 0)
+    const float* hk = h + kh * KH;
+    for (long s = 0; s < T; ++s) {
+        const long t = dir == 0 ? s : T - 1 - s;
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+        if (t_ < HQ) {
+            g0 = gid[(long)my_unit * T + t];
+            g1 = gid[(long)(HD + my_unit) * T + t];
+            g2 = gid[(long)(2 * HD + my_unit) * T + t];
+        }
+        float a0 = brow;
+#pragma unroll
+        for (int kb = 0; kb < KH; kb += 16) {
+            float hv[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) hv[q] = hk[kb + q];
+            float c0 = 0.f, c1 = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; q += 2) {
+                c0 = fmaf(wr[kb + q], hv[q], c0);
+                c1 = fmaf(wr[kb + q + 1], hv[q + 1], c1);
+            }
+            a0 += c0 + c1;
+            asm volatile("" : "+v"(a0));
+        }
+        gh[t_] = a0;
+        __syncthreads();
+        const int par = (int)(s & 1);
+        if (t_ < HQ) {
+            const float r = 1.f / (1.f + expf(-(g0 + (gh[u] + gh[NR + u]))));
+            const float z = 1.f / (1.f + expf(-(g1 + (gh[HQ + u] + gh[NR + HQ + u]))));
+            const float n = tanhf(g2 + r * (gh[2 * HQ + u] + gh[NR + 2 * HQ + u]));
+            const float hn = (1.f - z) * n + z * h[my_unit];
+            h[my_unit] = hn;
+            od[(long)my_unit * T + t] = hn;
+            const unsigned long long gran = ((unsigned long long)(unsigned)(s + 1) << 32) | (unsigned)__float_as_int(hn);
+            if (same_xcd) mine[par * HQ + u] = gran;
+            else __hip_atomic_store(mine + par * HQ + u, gran, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (t_ < 4 * HQ) {
+            // other WAVES than the publishers (see gru2_kernel): one lane per value of the three partners' quarters
+            const int v = t_ - HQ;
+            const int pp = (part + 1 + v / HQ) & 3, pu = v % HQ;
+            const unsigned long long* theirs = xbuf + ((long)(dir * 4 + pp) * 2) * HQ;
+            unsigned long long gran = 0;
+            const unsigned want = (unsigned)(s + 1);
+            int spins = 0;
+            for (;;) {
+                gran = __hip_atomic_load(theirs + par * HQ + pu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(gran >> 32) == want) break;
+                if (++spins > (1 << 22)) { *err = 1; break; }  // bounded: never hang the device
+                __builtin_amdgcn_s_sleep(1);
+            }
+            h[pp * HQ + pu] = __int_as_float((int)(unsigned)gran);
+        }
+        __syncthreads();
+        if ((s & 31) == 31 && *((volatile int*)err)) return;   // a timed-out partner: everybody leaves within 32 steps
+    }
+}
+
 // ---- salience decode: RMVPE.to_local_average_cents + decode (rmvpe.py:359-364, 385-409) -----------------------
 // salience: (T, NB=360) row-major fp32.  One wave per frame: argmax by xor-shuffles (first maximum wins, like
 // np.argmax), then lane 0 forms the 9-bin float64 local average in numpy's pairwise order for n = 9:
@@ -390,6 +512,28 @@ extern "C" int aicg_gru_bidir_2wg(const float* gi, const float* whh_t, const flo
         return fail(AICG_E_SHAPE, "aicg_gru_bidir_2wg: hidden size %d not instantiated (256, 64)", hidden);
     }
     return check_launch("gru2_kernel");
+}
+
+extern "C" int aicg_gru_bidir_4wg(const float* gi, const float* whh_t, const float* bhh, float* out, int hidden, int64_t T,
+                                  void* xchg_scratch, void* stream) {
+    // xchg_scratch: 2 dirs x 4 parts x 2 parities x hidden/4 granules of 8 bytes (= 32*hidden bytes) + 64 zeroed bytes (error word,
+    // XCC ids) -- the same size as aicg_gru_bidir_2wg's
+    if (!gi || !whh_t || !bhh || !out || !xchg_scratch) return fail(AICG_E_ARG, "aicg_gru_bidir_4wg: null pointer");
+    if (hidden != 256) return fail(AICG_E_SHAPE, "aicg_gru_bidir_4wg: hidden size %d not instantiated (256)", hidden);
+    if (T == 0) return AICG_OK;
+    const size_t xbytes = (size_t)2 * 4 * 2 * (hidden / 4) * 8;
+    (void)hipMemsetAsync(xchg_scratch, 0, xbytes + 64, (hipStream_t)stream);
+    unsigned long long* xb = (unsigned long long*)xchg_scratch;
+    int* err = (int*)((char*)xchg_scratch + xbytes);
+    AICG_SWITCH(force_agent, "AICG_GRU_AGENT_STORES", 0);  // A/B switch
+#ifdef AICG_EMULATED
+    const unsigned nblocks = 8;
+#else
+    const unsigned nblocks = 32;
+#endif
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(gru4_kernel<256>), dim3(nblocks), dim3(384), 0, (hipStream_t)stream, gi, whh_t, bhh, out, (long)T,
+                       xb, err, (int)force_agent);
+    return check_launch("gru4_kernel");
 }
 
 extern "C" int aicg_salience_decode(const float* salience, double* cents, double* f0, int* center, int64_t T, int n_bins,

@@ -560,7 +560,8 @@ def avgpool2x2(x):
     return out
 
 
-GRU_TWO_WORKGROUPS = os.environ.get("AICG_GRU_2WG", "1") != "0"
+GRU_TWO_WORKGROUPS = os.environ.get("AICG_GRU_2WG", "1") != "0"     # "0": the single-workgroup kernel (no co-residency needed)
+GRU_WORKGROUPS = int(os.environ.get("AICG_GRU_WG", "4"))             # workgroups per direction of the multi-workgroup form: 4 or 2
 
 
 _gru_pending = []
@@ -592,7 +593,9 @@ def gru_bidir(gi, whh_t, bhh, hidden, two_workgroups=None):
     _check(gi, whh_t, bhh)
     if GRU_TWO_WORKGROUPS if two_workgroups is None else two_workgroups:
         scratch = torch.empty(32 * hidden + 64, dtype=torch.uint8, device=gi.device)
-        _call("aicg_gru_bidir_2wg", _ptr(gi), _ptr(whh_t), _ptr(bhh), _ptr(out), hidden, t, _ptr(scratch), _stream(gi))
+        # hidden 256 (every RMVPE): four workgroups per direction, all of W_hh in registers; other sizes: two (part of it in LDS)
+        _call("aicg_gru_bidir_4wg" if hidden == 256 and GRU_WORKGROUPS == 4 else "aicg_gru_bidir_2wg", _ptr(gi), _ptr(whh_t), _ptr(bhh),
+              _ptr(out), hidden, t, _ptr(scratch), _stream(gi))
         # the kernel's exchange-timeout flag is read back lazily (gru_check_pending): an .item() here would park the host
         # until the recurrence ends, which is exactly the time pipeline() wants to spend queueing HuBERT work
         _gru_pending.append(scratch[32 * hidden: 32 * hidden + 4].view(torch.int32))
@@ -631,8 +634,9 @@ def f0_coarse(f0, factor, mel_min, mel_max):
 # ---------------------------------------------------------------------------------------------------
 # MDX-Net helpers
 # ---------------------------------------------------------------------------------------------------
-def linear_last(x, weight, bias=None, ch_scale=None, ch_shift=None, act=ACT_NONE, res=None, out=None):
-    """nn.Linear over the last axis of a contiguous (B, C, T, F) map (+ per-channel affine, act, residual)."""
+def linear_last(x, weight, bias=None, ch_scale=None, ch_shift=None, act=ACT_NONE, res=None, out=None, fp32=False):
+    """nn.Linear over the last axis of a contiguous (B, C, T, F) map (+ per-channel affine, act, residual).  `fp32`: never the
+    split-precision kernel (layers that select indices: CREPE)."""
     assert x.is_contiguous() and x.dim() == 4 and weight.is_contiguous()
     b, c, t, f = x.shape
     o = weight.shape[0]
@@ -642,7 +646,7 @@ def linear_last(x, weight, bias=None, ch_scale=None, ch_shift=None, act=ACT_NONE
     if res is not None:
         assert res.is_contiguous() and res.shape == out.shape
     _check(x, weight, bias, ch_scale, ch_shift, res, out)
-    _call("aicg_gemm_nt_split" if split_precision else "aicg_gemm_nt", _ptr(x), _ptr(weight), _ptr(bias), _ptr(ch_scale),
+    _call("aicg_gemm_nt_split" if split_precision and not fp32 else "aicg_gemm_nt", _ptr(x), _ptr(weight), _ptr(bias), _ptr(ch_scale),
           _ptr(ch_shift), _ptr(res), _ptr(out), b * c * t, f, o, f, f, o, o, t, c, act, _stream(x))
     return out
 
@@ -954,8 +958,15 @@ def _numel(*ts):
 
 stft = _staged("stft", stft, lambda a, k, r: (0.0, 4.0 * _numel(a[0], r)))
 istft = _staged("istft", istft, lambda a, k, r: (0.0, 4.0 * _numel(a[0], r)))
-linear_last = _staged("tdf_gemm_nt", linear_last, lambda a, k, r: (2.0 * r.numel() * a[1].shape[1],
-                                                                   4.0 * _numel(a[0], a[1], r, k.get("res"))))
+def dense_nt(x, weight, bias=None, act=ACT_NONE):
+    """act(x @ weight.T + bias) for a contiguous (rows, K) matrix on the fp32 NT GEMM (CREPE's Toeplitz layers and classifier)."""
+    return _linear_last_raw(x.view(1, 1, x.shape[0], x.shape[1]), weight, bias, act=act, fp32=True).view(x.shape[0], weight.shape[0])
+
+
+_linear_last_raw = linear_last
+_gemm_work = lambda a, k, r: (2.0 * r.numel() * a[1].shape[1], 4.0 * _numel(a[0], a[1], r, k.get("res")))
+linear_last = _staged("tdf_gemm_nt", linear_last, _gemm_work)
+dense_nt = _staged("dense_gemm_nt", dense_nt, _gemm_work)
 attention = _staged("attention", attention, lambda a, k, r: (4.0 * a[0].numel() * a[0].shape[1],      # 4 T^2 D per head
                                                              4.0 * _numel(a[0], a[1], a[2], r)))
 sine_source = _staged("sine_source", sine_source, lambda a, k, r: (0.0, 4.0 * _numel(a[0], a[1], r)))

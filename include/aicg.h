@@ -209,6 +209,11 @@ int aicg_gru_bidir(const float* gi, const float* whh_t, const float* bhh, float*
  * xchg_scratch: 32 * hidden + 64 bytes of device memory (zeroed by the call); the last int is set to 1 on a spin timeout. */
 int aicg_gru_bidir_2wg(const float* gi, const float* whh_t, const float* bhh, float* out, int hidden, int64_t T,
                        void* xchg_scratch, void* stream);
+/* The same recurrence with each direction split over FOUR workgroups (hidden = 256 only): all recurrent weights in registers, half
+ * the dot product per step, the three partners' quarters fetched in one poll round.  Same scratch size and error protocol as
+ * aicg_gru_bidir_2wg (the exchange-timeout word is the first int behind the 32 * hidden granule bytes). */
+int aicg_gru_bidir_4wg(const float* gi, const float* whh_t, const float* bhh, float* out, int hidden, int64_t T,
+                       void* xchg_scratch, void* stream);
 /* RMVPE.decode / to_local_average_cents (src/rmvpe.py:359-364,385-409).  salience: (T, n_bins) row-major fp32;
  * cents, f0: (T) float64 (bit-equal to the numpy reference given identical salience); center: (T) argmax or NULL. */
 int aicg_salience_decode(const float* salience, double* cents, double* f0, int* center, int64_t T, int n_bins,

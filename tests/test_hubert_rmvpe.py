@@ -135,8 +135,8 @@ def test_rmvpe_full_matches_oracle():
 
 @pytest.mark.parametrize("hidden,T", [(64, 50), (256, 33)])
 def test_gru_kernels_match_torch(dev, hidden, T):
-    """Both recurrence kernels (single workgroup per direction; two co-resident workgroups exchanging h through tagged
-    granules) vs torch.nn.GRU semantics written out in oracle/rmvpe.py::bigru."""
+    """All recurrence kernels (single workgroup per direction; two, and for hidden 256 four, co-resident workgroups exchanging h
+    through tagged granules) vs torch.nn.GRU semantics written out in oracle/rmvpe.py::bigru."""
     torch.manual_seed(hidden)
     if dev.big:
         T = T * 40 + 3
@@ -152,10 +152,15 @@ def test_gru_kernels_match_torch(dev, hidden, T):
                     for s in ("", "_reverse")], 0).contiguous()
     whh_t = torch.stack([sd["fc.0.gru.weight_hh_l0"].t().contiguous(), sd["fc.0.gru.weight_hh_l0_reverse"].t().contiguous()])
     bhh = torch.cat([sd["fc.0.gru.bias_hh_l0"], sd["fc.0.gru.bias_hh_l0_reverse"]])
-    for two in (False, True):
-        got = ops.gru_bidir(dev.t(gi), dev.t(whh_t.contiguous()), dev.t(bhh), hidden, two_workgroups=two)
-        ops.gru_check_pending()
-        assert rel_rms(got, ref) < 1e-5, "two_workgroups=%s" % two
+    old = ops.GRU_WORKGROUPS
+    try:
+        for multi, nwg in ((False, 0), (True, 2), (True, 4)):
+            ops.GRU_WORKGROUPS = nwg
+            got = ops.gru_bidir(dev.t(gi), dev.t(whh_t.contiguous()), dev.t(bhh), hidden, two_workgroups=multi)
+            ops.gru_check_pending()
+            assert rel_rms(got, ref) < 1e-5, "workgroups per direction: %d" % (nwg or 1)
+    finally:
+        ops.GRU_WORKGROUPS = old
 
 
 @pytest.mark.gpu
