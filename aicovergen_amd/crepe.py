@@ -51,6 +51,11 @@ class Crepe:
             elif 2 * width <= w.shape[-1]:                      # at least half of every output's taps fall on the padding
                 pc = _ToeplitzGemm(w, b, width, 31, dev)
                 width //= 2
+            elif width < 128:
+                # a frame offers fewer positions than a 128-position tile: the same 64-tap convolution as a 1 x 64 kernel over the
+                # (frame, position) plane -- tiles then span several frames (a view of the batch, no data movement)
+                pc = _RowConv(w, b, 31, dev)
+                width //= 2
             else:
                 pc = ops.PackedConv(w, b, padding=31, padding_end=32, device=dev)
                 width //= 2
@@ -67,9 +72,25 @@ class Crepe:
         xp = F.pad(frames, (254, 254))                                      # zero padding of the first conv
         x = xp.view(b, 383, 4).transpose(1, 2).contiguous()                 # 4-phase view X[ph][q] = xpad[4q + ph]
         for i, (pc, s, t) in enumerate(self.layers):
-            x = pc(x) if isinstance(pc, _ToeplitzGemm) else ops.conv(x, pc, act=ops.ACT_RELU)
+            x = pc(x) if isinstance(pc, (_ToeplitzGemm, _RowConv)) else ops.conv(x, pc, act=ops.ACT_RELU)
             x = ops.affine_maxpool2(x, s, t)
         return ops.dense_nt(x.view(b, -1), self.fc_w, self.fc_b, act=ops.ACT_SIGMOID)
+
+
+class _RowConv:
+    """relu(conv1d(x, w, b)) of a (B, Cin, W) batch, padded `pad_left` / k - 1 - pad_left, evaluated as a 2-D convolution with a 1 x k
+    kernel on the batch re-laid-out as ONE (1, Cin, B, W) image: the implicit-GEMM tiles (128 positions) then cover 128 / W frames
+    instead of leaving 1 - W / 128 of a tile empty.  (A strided view is not enough: the kernel's range-checked buffer loads assume
+    a channel's rows lie inside its channel stride; the two re-layouts move 2 x 67 MB per 2048-frame batch, ~50 us.)"""
+
+    def __init__(self, w, b, pad_left, dev):
+        k = w.shape[-1]
+        self.pc = ops.PackedConv(w.unsqueeze(2), b, padding=(0, pad_left), padding_end=(0, k - 1 - pad_left), device=dev)
+
+    def __call__(self, x):
+        b, c, w = x.shape
+        y = ops.conv(x.permute(1, 0, 2).contiguous().unsqueeze(0), self.pc, act=ops.ACT_RELU)   # (1, Cout, B, W)
+        return y[0].permute(1, 0, 2).contiguous()
 
 
 class _ToeplitzGemm:

@@ -299,6 +299,8 @@ def conv(x, pc, res=None, out=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NON
     n, c, h, w = x4.shape
     assert c == pc.cin, "conv: input has %d channels, layer expects %d" % (c, pc.cin)
     assert x4.stride(3) == 1 or w == 1
+    # the kernels' range-checked buffer loads bound a channel chunk by its channel stride: a channel's rows must lie inside it
+    assert h == 1 or c == 1 or x4.stride(1) >= x4.stride(2) * (h - 1) + w, "conv: input rows must lie inside the channel stride"
     ho, wo = pc.out_hw(h, w)
     if out_len is not None:  # compute only the first out_len columns (e.g. SamePad of an even kernel)
         assert out_len <= wo

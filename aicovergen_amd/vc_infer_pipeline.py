@@ -223,16 +223,30 @@ class VC(object):
 
     def _vc_features(self, model, audio0, index, big_npy, index_rate, version, use_protect):
         """HuBERT features of one chunk (+ optional faiss index mix), reference :379-431.  Needs no pitch."""
-        # audio0: host array (reference contract) or a slice of the track already resident on the device
-        feats = audio0.float() if torch.is_tensor(audio0) else torch.from_numpy(np.ascontiguousarray(audio0)).float()
-        if feats.dim() == 2:
-            feats = feats.mean(-1)
-        assert feats.dim() == 1, feats.dim()
-        feats = feats.view(1, -1)
-        padding_mask = torch.zeros(feats.shape, dtype=torch.bool)
-        logits = model.extract_features(source=feats.to(self.device), padding_mask=padding_mask,
-                                        output_layer=9 if version == "v1" else 12)
-        feats = model.final_proj(logits[0]) if version == "v1" else logits[0]
+        return self._vc_features_many(model, [audio0], index, big_npy, index_rate, version, use_protect)[0]
+
+    def _vc_features_many(self, model, audios, index, big_npy, index_rate, version, use_protect):
+        """_vc_features for several chunks -> [(feats, feats0)].  A model with `extract_features_many` (aicovergen_amd.hubert) runs
+        the transformer's per-token layers once over all chunks; any other object with fairseq's `extract_features` is called
+        chunk by chunk, as the reference does."""
+        srcs = []
+        for audio0 in audios:
+            # audio0: host array (reference contract) or a slice of the track already resident on the device
+            feats = audio0.float() if torch.is_tensor(audio0) else torch.from_numpy(np.ascontiguousarray(audio0)).float()
+            if feats.dim() == 2:
+                feats = feats.mean(-1)
+            assert feats.dim() == 1, feats.dim()
+            srcs.append(feats.view(1, -1).to(self.device))
+        layer = 9 if version == "v1" else 12
+        if len(srcs) > 1 and hasattr(model, "extract_features_many"):
+            logits = model.extract_features_many(srcs, layer)
+        else:
+            logits = [model.extract_features(source=s, padding_mask=torch.zeros(s.shape, dtype=torch.bool), output_layer=layer)[0]
+                      for s in srcs]
+        return [self._vc_features_post(model, lg, index, big_npy, index_rate, version, use_protect) for lg in logits]
+
+    def _vc_features_post(self, model, logits, index, big_npy, index_rate, version, use_protect):
+        feats = model.final_proj(logits) if version == "v1" else logits
         feats0 = feats.clone() if use_protect else None
         if index is not None and hasattr(index, "mix_") and index_rate != 0:
             # device retrieval (aicovergen_amd.retrieval.FeatureIndex): faiss' search for the file's index type (IVF-Flat with
@@ -400,9 +414,9 @@ class VC(object):
             tf0 = ttime()
             with torch.cuda.stream(side):
                 f0_dev = self._rmvpe().infer_from_audio_device(pad_dev, thred=0.03, group=self._rmvpe_group())
-            for ci in mine:
-                s, e = bounds[ci]
-                feats_of[ci] = self._vc_features(model, pad_dev[s:e], index, big_npy, index_rate, version, use_protect)
+            many = self._vc_features_many(model, [pad_dev[bounds[ci][0]:bounds[ci][1]] for ci in mine], index, big_npy, index_rate,
+                                          version, use_protect)
+            feats_of = dict(zip(mine, many))
             main.synchronize()
             tf1 = ttime()
             side.synchronize()

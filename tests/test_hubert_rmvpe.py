@@ -34,6 +34,27 @@ def test_hubert_tiny_matches_oracle(dev):
         assert rel_rms(y1, ohub.extract_features(sd, cfg, wav, 1)) < 1e-4
 
 
+def test_hubert_many_chunks_at_once(dev):
+    """extract_features_many: the transformer's per-token layers run once over chunks of different lengths laid side by side;
+    every chunk must come out as from its own call (other GEMM tiles: fp32 summation order only) and match the oracle."""
+    cfg = weights.HUBERT_TINY
+    sd = weights.hubert_state_dict(cfg, 1234)
+    m = HubertModel(sd, cfg).to(dev.device)
+    torch.manual_seed(1)
+    wavs = [torch.randn(1, n) * 0.3 for n in (8123, 5000, 9999)]
+    many = m.extract_features_many([dev.t(w) for w in wavs], 12)
+    assert len(many) == 3
+    for w, y in zip(wavs, many):
+        alone, _ = m.extract_features(source=w, padding_mask=None, output_layer=12)
+        assert y.shape == alone.shape == (1, (w.shape[1] - 400) // 320 + 1, cfg["embed"])
+        assert rel_rms(y, alone) < 2e-6
+        with torch.no_grad():
+            assert rel_rms(y, ohub.extract_features(sd, cfg, w, 12)) < 1e-4
+    nine = m.extract_features_many([dev.t(w) for w in wavs[:2]], 9)
+    with torch.no_grad():
+        assert rel_rms(nine[1], ohub.extract_features(sd, cfg, wavs[1], 9)) < 1e-4
+
+
 def test_hubert_cfg_inferred_from_shapes():
     sd = weights.hubert_state_dict(weights.HUBERT_TINY, 1)
     cfg = _infer_cfg(sd)
