@@ -30,7 +30,14 @@ struct AttnArgs {
 };
 
 static constexpr int KT = 32;       // keys per tile
-static constexpr int KV_LD = 33;    // LDS row stride of K/V tiles (conflict-free column reads)
+static constexpr int V_LD4 = 9;     // float4 per V row in LDS (36 floats: 16-byte aligned rows, b128 reads of 16 consecutive rows hit 16
+                                    // distinct bank quads: 9 d mod 16 is a permutation)
+// Fragment layouts (r3; the convolution family's finding applies here too: every hand-over of LDS-loaded registers to the matrix
+// pipe costs ~50-64 cycles, so ONE ds_read_b128 per fragment feeds FOUR MFMA k-steps instead of one ds_read_b32 each):
+//   K tile   [d / 8][d & 1][key][4]   element e of the quad = channel 8 (d / 8) + 2 e + (d & 1): lane (key, half) reads plane
+//            (g, half) and owns the A operands of k-steps 4 g .. 4 g + 3 of S^T = K Q^T (k-step s contracts channels 2 s, 2 s + 1);
+//   V tile   [d][key], 36-float rows: lane (d, half) reads keys 8 q + 4 half .. + 3 -- exactly the key pairs MFMA steps
+//            4 q .. 4 q + 3 of O^T += V^T P^T contract against the S^T accumulator registers 4 q .. 4 q + 3.
 
 // Key tiles are software-pipelined: the K/V tile kt + 1 is loaded into registers while tile kt is consumed from LDS.
 // Few (query block, head) pairs exist for long single-head-group sequences (enc_p: 52 x 2), so the key range can be split over
@@ -39,8 +46,10 @@ template <int D>
 __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs p) {
     constexpr int DT = D / 32;
     constexpr int NL = D * KT / 256;  // K (and V) elements each thread stages per tile
-    __shared__ float Ks[D * KV_LD];
-    __shared__ float Vs[D * KV_LD];
+    constexpr int NQ = NL / 4;        // K quads (4 channels of one key) per thread
+    static_assert(NL % 4 == 0, "a thread stages whole K quads");
+    __shared__ __attribute__((aligned(16))) float4 Ks4[(D / 4) * KT];     // (D / 8) x 2 planes x 32 keys
+    __shared__ __attribute__((aligned(16))) float4 Vs4[D * V_LD4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int h = blockIdx.y;
@@ -66,17 +75,25 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs p) {
     const int per = idiv_up(ntiles, p.nsplit);
     const int kt_begin = blockIdx.z * per, kt_end = imin(ntiles, kt_begin + per);
     const int blk_q0 = blockIdx.x * 128;
-    float kpre[NL], vpre[NL];
+    float4 kpre[NQ];
+    float vpre[NL];
     auto prefetch = [&](int kt) {
         const int j0 = kt * KT;
+#pragma unroll
+        for (int e = 0; e < NQ; ++e) {   // K: quad (plane = 2 g + parity, key j): channels 8 g + parity + {0, 2, 4, 6}, coalesced along j
+            const int item = tid + e * 256;
+            const int plane = item >> 5, j = item & 31;
+            const bool ok = (j0 + j) < p.T;
+            const float* src = kh + (long)(8 * (plane >> 1) + (plane & 1)) * p.ldk + (ok ? j0 + j : 0);
+            const float t0 = src[0], t1 = src[2 * p.ldk], t2 = src[4 * p.ldk], t3 = src[6 * p.ldk];
+            kpre[e] = ok ? make_float4(t0, t1, t2, t3) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
         for (int e = 0; e < NL; ++e) {
             const int idx = tid + e * 256;
             const int d = idx >> 5, j = idx & 31;
             const bool ok = (j0 + j) < p.T;
-            const int jj = ok ? j0 + j : 0;
-            const float tk = kh[(long)d * p.ldk + jj], tv = vh[(long)d * p.ldv + jj];
-            kpre[e] = ok ? tk : 0.f;
+            const float tv = vh[(long)d * p.ldv + (ok ? j0 + j : 0)];
             vpre[e] = ok ? tv : 0.f;
         }
     };
@@ -85,11 +102,11 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs p) {
         const int j0 = kt * KT;
         __syncthreads();
 #pragma unroll
+        for (int e = 0; e < NQ; ++e) Ks4[tid + e * 256] = kpre[e];          // item index = (plane, key): the layout itself
+#pragma unroll
         for (int e = 0; e < NL; ++e) {
             const int idx = tid + e * 256;
-            const int d = idx >> 5, j = idx & 31;
-            Ks[d * KV_LD + j] = kpre[e];
-            Vs[d * KV_LD + j] = vpre[e];
+            reinterpret_cast<float*>(Vs4)[(idx >> 5) * (4 * V_LD4) + (idx & 31)] = vpre[e];
         }
         __syncthreads();
         if (kt + 1 < kt_end) prefetch(kt + 1);
@@ -97,10 +114,18 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs p) {
         f32x16 st;
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[r] = 0.f;
+        {
+            const float4* kf = Ks4 + half * KT + l31;
+            float4 a = kf[0];
 #pragma unroll
-        for (int s = 0; s < D / 2; ++s) {
-            const float a = Ks[(2 * s + half) * KV_LD + l31];
-            st = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qreg[s], st, 0, 0, 0);
+            for (int g = 0; g < D / 8; ++g) {
+                const float4 an = kf[(g + 1 < D / 8 ? g + 1 : g) * 2 * KT];     // next k-group's quad in flight under these MFMAs
+                st = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qreg[4 * g], st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * g + 1], st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * g + 2], st, 0, 0, 0);
+                st = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * g + 3], st, 0, 0, 0);
+                a = an;
+            }
         }
         // relative-position key bias on the band |j - i| <= window (only near-diagonal tiles)
         if (p.relk && j0 + KT - 1 >= blk_q0 - p.window && j0 <= blk_q0 + 127 + p.window) {
@@ -140,14 +165,18 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs p) {
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[dt][r] *= alpha;
-        // O^T += V^T P^T : step r contracts keys (j_r, j_r + 4)
+        // O^T += V^T P^T : step r contracts keys (j_r, j_r + 4), j_r = (r & 3) + 8 (r >> 2); the quad q = r >> 2 of a V row is one float4
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int jr = (r & 3) + 8 * (r >> 2) + 4 * half;
+        for (int q = 0; q < 4; ++q) {
+            float4 a[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) a[dt] = Vs4[(dt * 32 + l31) * V_LD4 + 2 * q + half];
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                const float a = Vs[(dt * 32 + l31) * KV_LD + jr];
-                acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, st[r], acc[dt], 0, 0, 0);
+                acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[dt].x, st[4 * q], acc[dt], 0, 0, 0);
+                acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[dt].y, st[4 * q + 1], acc[dt], 0, 0, 0);
+                acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[dt].z, st[4 * q + 2], acc[dt], 0, 0, 0);
+                acc[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[dt].w, st[4 * q + 3], acc[dt], 0, 0, 0);
             }
         }
     }

@@ -612,7 +612,10 @@ __global__ void __launch_bounds__(512, 4) conv_ws3m16h_kernel(ConvArgs p) {
 
 template <int BM>
 static int launch_conv_ws3m16h(ConvArgs& p, hipStream_t stream) {
-    constexpr int BN = 256, KS = KSTAGE;
+    // KS = 72 K rows per weight stage = all nine taps of a 3 x 3 layer's 8-channel chunk (these layers' patches fit 8 channels): one
+    // stage per chunk -- 9 k-groups, ~6 900 MFMA cycles -- instead of two of 5 + 4 with KS = 64: half the stage barriers, and a
+    // producer's loads get a whole chunk's MFMAs (> one HBM round trip under load) to land
+    constexpr int BN = 256, KS = 72;
     if (p.Cin_g < 8 || !p.w3) return 1;
     p.TW = choose_tile_width(p, BN);
     p.TWlog2 = ilog2(p.TW);
