@@ -615,7 +615,9 @@ static int launch_conv_ws3m16h(ConvArgs& p, hipStream_t stream) {
     // KS = 72 K rows per weight stage = all nine taps of a 3 x 3 layer's 8-channel chunk (these layers' patches fit 8 channels): one
     // stage per chunk -- 9 k-groups, ~6 900 MFMA cycles -- instead of two of 5 + 4 with KS = 64: half the stage barriers, and a
     // producer's loads get a whole chunk's MFMAs (> one HBM round trip under load) to land
-    constexpr int BN = 256, KS = 72;
+    // (48-row layers: MDX level 0 118 -> 121 TFLOP/s; the 16-row kernel -- RMVPE level 0, one float4 weight copy per producer
+    //  thread at 64 rows, two at 72 -- measured slower with it and keeps 64)
+    constexpr int BN = 256, KS = BM == 48 ? 72 : 64;
     if (p.Cin_g < 8 || !p.w3) return 1;
     p.TW = choose_tile_width(p, BN);
     p.TWlog2 = ilog2(p.TW);

@@ -18,13 +18,15 @@ tail -40 $OUT/summary.log
 # opt-in split precision: kernel trace only (profiles/<tag>_split_kernel_stats.csv)
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_split -o bench -- $CMD --precision bf16x3 > $OUT/trace_split.log 2>&1
+timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/pmc_sq_split -o bench -- $CMD --precision bf16x3 > $OUT/pmc_sq_split.log 2>&1
 cd $GRAFT_REPO_ROOT
+python tools/summarize_profile.py $OUT $TAG split > $OUT/summary_split.log 2>&1
 cp $(find $OUT/trace_split -name "*kernel_stats.csv" | head -1) $OUT/split_kernel_stats.csv 2>/dev/null
 # the judged bench lines of this round
 python bench.py > $OUT/bench_c3_default.json 2> $OUT/bench_c3_default.err
-python bench.py --precision bf16x3 > $OUT/bench_c3_split.json 2> $OUT/bench_c3_split.err
+python bench.py --precision bf16x3 --no-cpu-baseline > $OUT/bench_c3_split.json 2> $OUT/bench_c3_split.err
 python bench.py --config C2 --no-cpu-baseline > $OUT/bench_c2.json 2>/dev/null
 python bench.py --config C4 --no-cpu-baseline > $OUT/bench_c4.json 2>/dev/null
+python bench.py --preset fp32 --no-cpu-baseline > $OUT/bench_c3_fp32preset.json 2>/dev/null
 python bench.py --mdx-models 3 --no-cpu-baseline > $OUT/bench_c3_3mdx.json 2>/dev/null
-python bench.py --mdx-models 3 --precision bf16x3 --no-cpu-baseline > $OUT/bench_c3_3mdx_split.json 2>/dev/null
 for f in $OUT/bench_*.json; do echo $f; cut -c1-200 $f; done
