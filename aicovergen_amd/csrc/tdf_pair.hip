@@ -1,0 +1,276 @@
+// The TDF block of the MDX-Net separator as ONE kernel:
+//     out = x + relu(bn2(relu(bn1(x W1^T + b1)) W2^T + b2))        x, out: (R, F) rows of a (B, C, T, F) map, W1: (H, F), W2: (F, H), H = F / bn
+// (reference: the graph onnxruntime executes at src/mdx.py:74-77,193; architecture: kuielab TFC_TDF).
+//
+// Two launches of the NT GEMM (gemm_nt.hip) ran this pair at 103 TFLOP/s (r2): the F -> H contraction re-reads x once per 128-column
+// tile of H (FETCH x 3.05), the (R, H) intermediate makes an HBM round trip, and the H -> F expansion has only H / 32 K-stages per
+// tile against a full tile epilogue.  Here a workgroup owns 128 rows:
+//   phase 1  four waves, 32 rows each, accumulate ALL H columns of their rows (H / 32 accumulator tiles per wave: up to 192 registers --
+//            one wave per SIMD, so the whole 512-entry register file is the wave's) over K-stages of 32 staged through LDS: W1 as
+//            [k / 8][k & 1][h][4] quads (its packed image in HBM has that order: float4 copies), x rows as [k / 8][k & 1][row][4]
+//            (two float4 loads -> two ds_write_b128 per 8 k of a row).  One ds_read_b128 per fragment per four MFMA k-steps,
+//            H / 32 + 1 fragments per 4 H / 32 MFMAs.  A stage is H / 8 MFMAs of 64 cycles per wave (12 288 cycles at H = 384): the
+//            same waves issue the next stage's 16 global loads at its start and commit them behind the barrier that ends it -- no
+//            producer waves, their registers would halve the budget of the accumulators.
+//   hand-over bias, BatchNorm (per row channel), ReLU in registers -- the intermediate NEVER leaves the register file:
+//   phase 2  out^T tile (32 f x 32 rows) += W2 tile (from LDS) x intermediate^T, with the phase-1 ACCUMULATOR REGISTERS as the B operand:
+//            register 4 q + e of tile i holds h = 32 i + 8 q + 4 half + e for this lane's row, so MFMA step (i, q, e) contracts the pair
+//            (h, h + 4) and lane half `half` of the A operand supplies W2[f][h + 4 half] -- four consecutive h: one ds_read_b128 of a
+//            natural row-major W2 row per four steps.  One LDS stage = 32 output columns; its epilogue (bias, BatchNorm, ReLU,
+//            + x, float4 stores: a lane owns 4 consecutive f per register quad) runs behind H / 8 MFMAs.
+// x is read twice (phase 1 operand, phase 2 residual), out written once, nothing else touches HBM but the L2-resident weights.
+#include "common.h"
+
+#include <cstdint>
+
+namespace aicg {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct TdfArgs {
+    const float* x;
+    const float* w1p;   // packed: [F / 8][2][H][4], element e of quad (g, par, h) = W1[h][8 g + 2 e + par]
+    const float* b1;
+    const float* s1;    // eval BatchNorm2d over the channel a row belongs to: ch = (row / rows_per_ch) % n_ch
+    const float* t1;
+    const float* w2;    // (F, H) row-major
+    const float* b2;
+    const float* s2;
+    const float* t2;
+    float* out;
+    long R;
+    int F, H, rows_per_ch, n_ch;
+};
+
+static constexpr int TR = 128;   // rows per workgroup
+static constexpr int TK = 32;    // K per phase-1 stage
+
+// LDS floats per stage buffer
+__host__ __device__ constexpr int tdf_stage_floats(int H) {
+    const int p1 = TK * H + TK * TR;          // W1 slab (8 planes x H quads) + x slab (8 planes x 128 quads)
+    const int p2 = 32 * (H + 4);              // W2 slab: 32 rows of H + 4
+    return p1 > p2 ? p1 : p2;
+}
+
+// Staging (all 256 threads).  Stage st < n1: K-slab st of phase 1 (W1 quads + x quads); stage n1 + fb: W2 rows of output block fb.
+// Buffer st & 1.
+template <int NH>
+__device__ __forceinline__ void tdf_load1(const TdfArgs& p, int pt, long r0, int st, float4 (&wv)[NH], float4 (&xv)[4]) {
+    constexpr int H = NH * 32;
+    const float4* src = reinterpret_cast<const float4*>(p.w1p) + (long)st * (TK / 4) * H;   // 8 planes of H quads, contiguous
+#pragma unroll
+    for (int e = 0; e < NH; ++e) wv[e] = src[pt + e * 256];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {                    // x: item = (8-k group, row); rows fastest: consecutive LDS quads
+        const int item = pt + e * 256;
+        const int row = item & (TR - 1), gg = item >> 7;
+        const long r = r0 + row;
+        const long rr = r < p.R ? r : 0;
+        const float4* xr = reinterpret_cast<const float4*>(p.x + rr * p.F + (long)st * TK + 8 * gg);
+        const float4 v0 = xr[0], v1 = xr[1];
+        const bool ok = r < p.R;
+        xv[2 * e] = ok ? v0 : make_float4(0.f, 0.f, 0.f, 0.f);
+        xv[2 * e + 1] = ok ? v1 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+template <int NH>
+__device__ __forceinline__ void tdf_commit1(float* buf, int pt, const float4 (&wv)[NH], const float4 (&xv)[4]) {
+    constexpr int H = NH * 32;
+    float4* wdst = reinterpret_cast<float4*>(buf);
+#pragma unroll
+    for (int e = 0; e < NH; ++e) wdst[pt + e * 256] = wv[e];
+    float4* xdst = reinterpret_cast<float4*>(buf + TK * H);
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int item = pt + e * 256;
+        const int row = item & (TR - 1), gg = item >> 7;
+        // k = 8 gg + 2 j + par: parity 0 takes elements 0, 2, 4, 6 of the 8 loaded values, parity 1 the odd ones
+        xdst[(gg * 2) * TR + row] = make_float4(xv[2 * e].x, xv[2 * e].z, xv[2 * e + 1].x, xv[2 * e + 1].z);
+        xdst[(gg * 2 + 1) * TR + row] = make_float4(xv[2 * e].y, xv[2 * e].w, xv[2 * e + 1].y, xv[2 * e + 1].w);
+    }
+}
+
+template <int NH>
+__device__ __forceinline__ void tdf_load2(const TdfArgs& p, int pt, int fb, float4 (&wv)[NH]) {
+    constexpr int H = NH * 32;
+#pragma unroll
+    for (int e = 0; e < NH; ++e) {
+        const int idx = pt + e * 256;                // (row of the slab, float4 along h)
+        const int row = idx / (H / 4), c4 = idx - row * (H / 4);
+        wv[e] = reinterpret_cast<const float4*>(p.w2 + (long)(fb * 32 + row) * H)[c4];
+    }
+}
+
+template <int NH>
+__device__ __forceinline__ void tdf_commit2(float* buf, int pt, const float4 (&wv)[NH]) {
+    constexpr int H = NH * 32;
+#pragma unroll
+    for (int e = 0; e < NH; ++e) {
+        const int idx = pt + e * 256;
+        const int row = idx / (H / 4), c4 = idx - row * (H / 4);
+        *reinterpret_cast<float4*>(buf + row * (H + 4) + 4 * c4) = wv[e];
+    }
+}
+
+template <int NH>
+__global__ void __launch_bounds__(256) tdf_pair_kernel(TdfArgs p) {
+    constexpr int H = NH * 32;
+    constexpr int STAGE = tdf_stage_floats(H);
+    constexpr int W2LD = H + 4;
+    HIP_DYNAMIC_SHARED(float, smem)
+    const int tid = threadIdx.x;
+    const long r0 = (long)blockIdx.x * TR;
+    const int n1 = p.F / TK;          // phase-1 stages
+    const int n2 = p.F / 32;          // phase-2 stages (32 output columns each)
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const long row = r0 + wave * 32 + l31;                 // this lane's row (the MFMA column)
+    const bool row_ok = row < p.R;
+    f32x16 acc[NH];
+#pragma unroll
+    for (int i = 0; i < NH; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    // staging registers: stage s + 1 is loaded while stage s computes and committed behind the barrier that opens stage s + 1's turn
+    float4 wv[NH], xv[4];
+    tdf_load1<NH>(p, tid, r0, 0, wv, xv);
+    tdf_commit1<NH>(smem, tid, wv, xv);
+    if (n1 > 1) tdf_load1<NH>(p, tid, r0, 1, wv, xv);
+    else tdf_load2<NH>(p, tid, 0, wv);
+    // ---- phase 1: acc[i] = (x W1^T)^T tile i: rows h = 32 i .. 32 i + 31, column = this lane's row
+    for (int st = 0; st < n1; ++st) {
+        lds_barrier();   // stage st is in LDS; every wave is done with stage st - 1, whose buffer takes stage st + 1 now
+        if (st + 1 < n1) {
+            tdf_commit1<NH>(smem + ((st + 1) & 1) * STAGE, tid, wv, xv);
+            if (st + 2 < n1) tdf_load1<NH>(p, tid, r0, st + 2, wv, xv);
+            else tdf_load2<NH>(p, tid, 0, wv);
+        } else {
+            tdf_commit2<NH>(smem + ((st + 1) & 1) * STAGE, tid, wv);
+            if (n2 > 1) tdf_load2<NH>(p, tid, 1, wv);
+        }
+        const float4* wq = reinterpret_cast<const float4*>(smem + (st & 1) * STAGE) + half * H + l31;
+        const float4* xq = reinterpret_cast<const float4*>(smem + (st & 1) * STAGE + TK * H) + half * TR + wave * 32 + l31;
+#pragma unroll
+        for (int g = 0; g < TK / 8; ++g) {
+            const float4 b = xq[g * 2 * TR];
+            float4 a = wq[g * 2 * H];
+#pragma unroll
+            for (int i = 0; i < NH; ++i) {
+                const float4 an = wq[g * 2 * H + (i + 1 < NH ? i + 1 : i) * 32];   // next tile's quad in flight under these MFMAs
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[i], 0, 0, 0);
+                a = an;
+            }
+        }
+    }
+    // ---- hand-over: bias + BatchNorm (the 32 rows of a wave share a channel: rows_per_ch % 32 == 0) + ReLU, in registers
+    const int ch = (int)(((r0 + wave * 32) / p.rows_per_ch) % p.n_ch);
+    {
+        const float sc = p.s1 ? p.s1[ch] : 1.f, sh = p.t1 ? p.t1[ch] : 0.f;
+#pragma unroll
+        for (int i = 0; i < NH; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bq = p.b1 ? *reinterpret_cast<const float4*>(p.b1 + 32 * i + 8 * q + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = (acc[i][4 * q + e] + bb[e]) * sc + sh;
+                    acc[i][4 * q + e] = v > 0.f ? v : 0.f;
+                }
+            }
+    }
+    // ---- phase 2: 32 output columns per stage
+    const float sc2 = p.s2 ? p.s2[ch] : 1.f, sh2 = p.t2 ? p.t2[ch] : 0.f;
+    const float* xrow = p.x + row * p.F;
+    float* orow = p.out + row * p.F;
+    for (int fb = 0; fb < n2; ++fb) {
+        const int st = n1 + fb;
+        lds_barrier();
+        if (fb + 1 < n2) {
+            tdf_commit2<NH>(smem + ((st + 1) & 1) * STAGE, tid, wv);
+            if (fb + 2 < n2) tdf_load2<NH>(p, tid, fb + 2, wv);
+        }
+        // residual x[row][32 fb + 8 q + 4 half .. + 3]: requested before the MFMAs, consumed behind them
+        float4 rx[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            rx[q] = row_ok ? *reinterpret_cast<const float4*>(xrow + 32 * fb + 8 * q + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4* w2q = reinterpret_cast<const float4*>(smem + (st & 1) * STAGE + l31 * W2LD) + half;   // row f = l31 of the slab
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.f;
+        float4 a = w2q[0];
+#pragma unroll
+        for (int i = 0; i < NH; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int nxt = (i * 4 + q + 1 < NH * 4) ? (i * 4 + q + 1) : (i * 4 + q);
+                const float4 an = w2q[(nxt >> 2) * 8 + (nxt & 3) * 2];          // float4 index of h = 32 i' + 8 q' (+ 4 half via the base)
+                o = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, acc[i][4 * q], o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, acc[i][4 * q + 1], o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, acc[i][4 * q + 2], o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, acc[i][4 * q + 3], o, 0, 0, 0);
+                a = an;
+            }
+        if (row_ok) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int f = 32 * fb + 8 * q + 4 * half;
+                const float4 bq = p.b2 ? *reinterpret_cast<const float4*>(p.b2 + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+                float e0 = (o[4 * q] + bq.x) * sc2 + sh2, e1 = (o[4 * q + 1] + bq.y) * sc2 + sh2;
+                float e2 = (o[4 * q + 2] + bq.z) * sc2 + sh2, e3 = (o[4 * q + 3] + bq.w) * sc2 + sh2;
+                e0 = (e0 > 0.f ? e0 : 0.f) + rx[q].x;
+                e1 = (e1 > 0.f ? e1 : 0.f) + rx[q].y;
+                e2 = (e2 > 0.f ? e2 : 0.f) + rx[q].z;
+                e3 = (e3 > 0.f ? e3 : 0.f) + rx[q].w;
+                *reinterpret_cast<float4*>(orow + f) = make_float4(e0, e1, e2, e3);
+            }
+        }
+    }
+}
+
+template <int NH>
+static int launch_tdf(const TdfArgs& p, hipStream_t st) {
+    const size_t lds = (size_t)2 * tdf_stage_floats(NH * 32) * sizeof(float);
+    allow_dynamic_lds((const void*)tdf_pair_kernel<NH>, lds);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(tdf_pair_kernel<NH>), dim3((unsigned)ldiv_up(p.R, TR)), dim3(256), lds, st, p);
+    return check_launch("tdf_pair_kernel");
+}
+
+}  // namespace aicg
+
+using namespace aicg;
+
+extern "C" int aicg_tdf_pair_supported(int F, int H, int rows_per_ch) {
+    const int nh = H / 32;
+    return (H % 32 == 0 && (nh == 2 || nh == 3 || nh == 4 || nh == 6 || nh == 8 || nh == 12) && F % 32 == 0 && rows_per_ch % 32 == 0) ? 1 : 0;
+}
+
+extern "C" int aicg_tdf_pair(const float* x, const float* w1_packed, const float* b1, const float* s1, const float* t1, const float* w2,
+                             const float* b2, const float* s2, const float* t2, float* out, int64_t R, int F, int H, int rows_per_ch,
+                             int n_ch, void* stream) {
+    if (!x || !w1_packed || !w2 || !out) return fail(AICG_E_ARG, "aicg_tdf_pair: null pointer");
+    if ((s1 != nullptr) != (t1 != nullptr) || (s2 != nullptr) != (t2 != nullptr)) return fail(AICG_E_ARG, "aicg_tdf_pair: scale without shift");
+    if (!aicg_tdf_pair_supported(F, H, rows_per_ch) || n_ch < 1)
+        return fail(AICG_E_SHAPE, "aicg_tdf_pair: needs H in 32 x {2,3,4,6,8,12}, F %% 32 == 0, rows_per_ch %% 32 == 0 (F %d, H %d, rows %d)", F, H, rows_per_ch);
+    auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    if (!al(x) || !al(w1_packed) || !al(w2) || !al(out) || (b1 && !al(b1)) || (b2 && !al(b2)))
+        return fail(AICG_E_ARG, "aicg_tdf_pair: operands must be 16-byte aligned");
+    if (R <= 0) return AICG_OK;
+    TdfArgs p{x, w1_packed, b1, s1, t1, w2, b2, s2, t2, out, (long)R, F, H, rows_per_ch, n_ch};
+    hipStream_t st = (hipStream_t)stream;
+    switch (H / 32) {
+        case 2: return launch_tdf<2>(p, st);
+        case 3: return launch_tdf<3>(p, st);
+        case 4: return launch_tdf<4>(p, st);
+        case 6: return launch_tdf<6>(p, st);
+        case 8: return launch_tdf<8>(p, st);
+        default: return launch_tdf<12>(p, st);
+    }
+}

@@ -653,6 +653,31 @@ def linear_last(x, weight, bias=None, ch_scale=None, ch_shift=None, act=ACT_NONE
     return out
 
 
+def pack_tdf_w1(w1):
+    """(H, F) -> [F / 8][2][H][4]: element e of quad (g, par, h) = W1[h][8 g + 2 e + par] (aicg_tdf_pair's w1_packed)."""
+    h, f = w1.shape
+    assert f % 8 == 0
+    return w1.detach().float().t().reshape(f // 8, 4, 2, h).permute(0, 2, 3, 1).contiguous()
+
+
+def tdf_pair_supported(f, h, rows_per_ch):
+    return bool(_lib.get().aicg_tdf_pair_supported(int(f), int(h), int(rows_per_ch)))
+
+
+def tdf_pair(x, w1p, b1, s1, t1, w2, b2, s2, t2, out=None):
+    """x + relu(bn2(relu(bn1(x W1^T + b1)) W2^T + b2)) over the last axis of a contiguous (B, C, T, F) map, one launch."""
+    assert x.is_contiguous() and x.dim() == 4 and w2.is_contiguous() and w1p.is_contiguous()
+    b, c, t, f = x.shape
+    h = w2.shape[1]
+    assert w2.shape[0] == f and w1p.numel() == f * h
+    if out is None:
+        out = torch.empty_like(x)
+    _check(x, w1p, b1, s1, t1, w2, b2, s2, t2, out)
+    _call("aicg_tdf_pair", _ptr(x), _ptr(w1p), _ptr(b1), _ptr(s1), _ptr(t1), _ptr(w2), _ptr(b2), _ptr(s2), _ptr(t2), _ptr(out),
+          b * c * t, f, h, t, c, _stream(x))
+    return out
+
+
 def mul(a, b, out=None):
     assert a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
     if out is None:
@@ -968,6 +993,8 @@ def dense_nt(x, weight, bias=None, act=ACT_NONE):
 _linear_last_raw = linear_last
 _gemm_work = lambda a, k, r: (2.0 * r.numel() * a[1].shape[1], 4.0 * _numel(a[0], a[1], r, k.get("res")))
 linear_last = _staged("tdf_gemm_nt", linear_last, _gemm_work)
+tdf_pair = _staged("tdf_pair", tdf_pair, lambda a, k, r: (4.0 * a[0].numel() * a[5].shape[1],      # 2 GEMMs of R x F x H
+                                                          4.0 * _numel(a[0], a[0], r, a[1], a[5])))  # x twice (operand + residual), out
 dense_nt = _staged("dense_gemm_nt", dense_nt, _gemm_work)
 attention = _staged("attention", attention, lambda a, k, r: (4.0 * a[0].numel() * a[0].shape[1],      # 4 T^2 D per head
                                                              4.0 * _numel(a[0], a[1], a[2], r)))
