@@ -16,7 +16,7 @@
 //   phase 2  out^T tile (32 f x 32 rows) += W2 tile (from LDS) x intermediate^T, with the phase-1 ACCUMULATOR REGISTERS as the B operand:
 //            register 4 q + e of tile i holds h = 32 i + 8 q + 4 half + e for this lane's row, so MFMA step (i, q, e) contracts the pair
 //            (h, h + 4) and lane half `half` of the A operand supplies W2[f][h + 4 half] -- four consecutive h: one ds_read_b128 of a
-//            natural row-major W2 row per four steps.  One LDS stage = 32 output columns; its epilogue (bias, BatchNorm, ReLU,
+//            row-major W2 row per four steps.  One LDS stage = 32 output columns; its epilogue (bias, BatchNorm, ReLU,
 //            + x, float4 stores: a lane owns 4 consecutive f per register quad) runs behind H / 8 MFMAs.
 // x is read twice (phase 1 operand, phase 2 residual), out written once, nothing else touches HBM but the L2-resident weights.
 #include "common.h"
@@ -33,7 +33,7 @@ struct TdfArgs {
     const float* b1;
     const float* s1;    // eval BatchNorm2d over the channel a row belongs to: ch = (row / rows_per_ch) % n_ch
     const float* t1;
-    const float* w2;    // (F, H) row-major
+    const float* w2p;   // packed: [F / 32] slabs of tdf_w2_slab_floats(H): 32 rows of H + 4 floats (W2 rows, zero padded)
     const float* b2;
     const float* s2;
     const float* t2;
@@ -45,72 +45,63 @@ struct TdfArgs {
 static constexpr int TR = 128;   // rows per workgroup
 static constexpr int TK = 32;    // K per phase-1 stage
 
+// floats of one packed W2 slab: 32 rows of H + 4 (row padding against LDS bank conflicts), rounded up to whole 1 KiB DMA pieces
+__host__ __device__ constexpr int tdf_w2_slab_floats(int H) { return (32 * (H + 4) + 255) / 256 * 256; }
+
 // LDS floats per stage buffer
 __host__ __device__ constexpr int tdf_stage_floats(int H) {
     const int p1 = TK * H + TK * TR;          // W1 slab (8 planes x H quads) + x slab (8 planes x 128 quads)
-    const int p2 = 32 * (H + 4);              // W2 slab: 32 rows of H + 4
+    const int p2 = tdf_w2_slab_floats(H);     // W2 slab: 32 rows of H + 4
     return p1 > p2 ? p1 : p2;
 }
 
 // Staging (all 256 threads).  Stage st < n1: K-slab st of phase 1 (W1 quads + x quads); stage n1 + fb: W2 rows of output block fb.
-// Buffer st & 1.
-template <int NH>
-__device__ __forceinline__ void tdf_load1(const TdfArgs& p, int pt, long r0, int st, float4 (&wv)[NH], float4 (&xv)[4]) {
-    constexpr int H = NH * 32;
-    const float4* src = reinterpret_cast<const float4*>(p.w1p) + (long)st * (TK / 4) * H;   // 8 planes of H quads, contiguous
-#pragma unroll
-    for (int e = 0; e < NH; ++e) wv[e] = src[pt + e * 256];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {                    // x: item = (8-k group, row); rows fastest: consecutive LDS quads
-        const int item = pt + e * 256;
-        const int row = item & (TR - 1), gg = item >> 7;
-        const long r = r0 + row;
-        const long rr = r < p.R ? r : 0;
-        const float4* xr = reinterpret_cast<const float4*>(p.x + rr * p.F + (long)st * TK + 8 * gg);
-        const float4 v0 = xr[0], v1 = xr[1];
-        const bool ok = r < p.R;
-        xv[2 * e] = ok ? v0 : make_float4(0.f, 0.f, 0.f, 0.f);
-        xv[2 * e + 1] = ok ? v1 : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+// Buffer st & 1.  The weight slabs are plain contiguous copies -- both images are laid out in HBM exactly as LDS wants them (W2 with
+// its row padding materialised) -- and go HBM -> LDS by DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, lane-linear
+// destination, no staging registers: the accumulators need them); only the x slab, whose 8 consecutive k per row are dealt to
+// two parity planes, passes through registers (four float4).
+__device__ __forceinline__ void lds_dma16(const float* g, float* lds_wave_base, int lane) {
+#ifdef AICG_EMULATED
+    *reinterpret_cast<float4*>(lds_wave_base + 4 * lane) = *reinterpret_cast<const float4*>(g);
+#else
+    (void)lane;
+    __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+#endif
+}
+// every DMA this wave issued has landed (the LDS-only barrier behind it publishes the stage)
+__device__ __forceinline__ void dma_wait() {
+#ifndef AICG_EMULATED
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 }
 
-template <int NH>
-__device__ __forceinline__ void tdf_commit1(float* buf, int pt, const float4 (&wv)[NH], const float4 (&xv)[4]) {
-    constexpr int H = NH * 32;
-    float4* wdst = reinterpret_cast<float4*>(buf);
-#pragma unroll
-    for (int e = 0; e < NH; ++e) wdst[pt + e * 256] = wv[e];
-    float4* xdst = reinterpret_cast<float4*>(buf + TK * H);
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int item = pt + e * 256;
-        const int row = item & (TR - 1), gg = item >> 7;
-        // k = 8 gg + 2 j + par: parity 0 takes elements 0, 2, 4, 6 of the 8 loaded values, parity 1 the odd ones
-        xdst[(gg * 2) * TR + row] = make_float4(xv[2 * e].x, xv[2 * e].z, xv[2 * e + 1].x, xv[2 * e + 1].z);
-        xdst[(gg * 2 + 1) * TR + row] = make_float4(xv[2 * e].y, xv[2 * e].w, xv[2 * e + 1].y, xv[2 * e + 1].w);
-    }
+// n4 float4 (a multiple of 64) from src to dst, spread over the workgroup's four waves
+__device__ __forceinline__ void tdf_dma_slab(const float* src, float* dst, int n4, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int c = wave * 64; c < n4; c += 256) lds_dma16(src + 4 * (c + lane), dst + 4 * c, lane);
 }
 
-template <int NH>
-__device__ __forceinline__ void tdf_load2(const TdfArgs& p, int pt, int fb, float4 (&wv)[NH]) {
-    constexpr int H = NH * 32;
-#pragma unroll
-    for (int e = 0; e < NH; ++e) {
-        const int idx = pt + e * 256;                // (row of the slab, float4 along h)
-        const int row = idx / (H / 4), c4 = idx - row * (H / 4);
-        wv[e] = reinterpret_cast<const float4*>(p.w2 + (long)(fb * 32 + row) * H)[c4];
-    }
+struct XStage { float4 a0, a1, b0, b1; };   // two (row, 8-k group) items of the x slab
+
+__device__ __forceinline__ void tdf_load_x(const TdfArgs& p, int tid, long r0, int st, XStage& v) {
+    // item = (8-k group, row); rows fastest: consecutive LDS quads.  Items tid and tid + 256: groups gg and gg + 2 of row tid & 127
+    const int row = tid & (TR - 1), gg = tid >> 7;
+    const long r = r0 + row;
+    const bool ok = r < p.R;
+    const float4* xr = reinterpret_cast<const float4*>(p.x + (ok ? r : 0) * p.F + (long)st * TK + 8 * gg);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 t0 = xr[0], t1 = xr[1], t2 = xr[4], t3 = xr[5];   // + 16 floats: group gg + 2
+    v.a0 = ok ? t0 : z; v.a1 = ok ? t1 : z; v.b0 = ok ? t2 : z; v.b1 = ok ? t3 : z;
 }
 
-template <int NH>
-__device__ __forceinline__ void tdf_commit2(float* buf, int pt, const float4 (&wv)[NH]) {
-    constexpr int H = NH * 32;
-#pragma unroll
-    for (int e = 0; e < NH; ++e) {
-        const int idx = pt + e * 256;
-        const int row = idx / (H / 4), c4 = idx - row * (H / 4);
-        *reinterpret_cast<float4*>(buf + row * (H + 4) + 4 * c4) = wv[e];
-    }
+__device__ __forceinline__ void tdf_commit_x(float* xbuf, int tid, const XStage& v) {
+    const int row = tid & (TR - 1), gg = tid >> 7;
+    float4* xdst = reinterpret_cast<float4*>(xbuf);
+    // k = 8 g + 2 j + par: parity 0 takes elements 0, 2, 4, 6 of the 8 loaded values, parity 1 the odd ones
+    xdst[(gg * 2) * TR + row] = make_float4(v.a0.x, v.a0.z, v.a1.x, v.a1.z);
+    xdst[(gg * 2 + 1) * TR + row] = make_float4(v.a0.y, v.a0.w, v.a1.y, v.a1.w);
+    xdst[((gg + 2) * 2) * TR + row] = make_float4(v.b0.x, v.b0.z, v.b1.x, v.b1.z);
+    xdst[((gg + 2) * 2 + 1) * TR + row] = make_float4(v.b0.y, v.b0.w, v.b1.y, v.b1.w);
 }
 
 template <int NH>
@@ -134,22 +125,24 @@ __global__ void __launch_bounds__(256) tdf_pair_kernel(TdfArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    // staging registers: stage s + 1 is loaded while stage s computes and committed behind the barrier that opens stage s + 1's turn
-    float4 wv[NH], xv[4];
-    tdf_load1<NH>(p, tid, r0, 0, wv, xv);
-    tdf_commit1<NH>(smem, tid, wv, xv);
-    if (n1 > 1) tdf_load1<NH>(p, tid, r0, 1, wv, xv);
-    else tdf_load2<NH>(p, tid, 0, wv);
+    // Stage s + 1 is fetched while stage s computes: weight slab by DMA straight into the other buffer, x slab into four registers
+    // committed at the end of the stage; the barrier that opens stage s + 1 follows this wave's vmcnt(0).
+    constexpr int W1Q = TK * H / 4;                       // float4 per W1 slab
+    constexpr int W2Q = tdf_w2_slab_floats(H) / 4;        // float4 per W2 slab
+    XStage xs;
+    tdf_dma_slab(p.w1p, smem, W1Q, tid);
+    tdf_load_x(p, tid, r0, 0, xs);
+    tdf_commit_x(smem + TK * H, tid, xs);
+    dma_wait();
     // ---- phase 1: acc[i] = (x W1^T)^T tile i: rows h = 32 i .. 32 i + 31, column = this lane's row
     for (int st = 0; st < n1; ++st) {
         lds_barrier();   // stage st is in LDS; every wave is done with stage st - 1, whose buffer takes stage st + 1 now
+        float* nbuf = smem + ((st + 1) & 1) * STAGE;
         if (st + 1 < n1) {
-            tdf_commit1<NH>(smem + ((st + 1) & 1) * STAGE, tid, wv, xv);
-            if (st + 2 < n1) tdf_load1<NH>(p, tid, r0, st + 2, wv, xv);
-            else tdf_load2<NH>(p, tid, 0, wv);
+            tdf_dma_slab(p.w1p + (long)(st + 1) * W1Q * 4, nbuf, W1Q, tid);
+            tdf_load_x(p, tid, r0, st + 1, xs);
         } else {
-            tdf_commit2<NH>(smem + ((st + 1) & 1) * STAGE, tid, wv);
-            if (n2 > 1) tdf_load2<NH>(p, tid, 1, wv);
+            tdf_dma_slab(p.w2p, nbuf, W2Q, tid);
         }
         const float4* wq = reinterpret_cast<const float4*>(smem + (st & 1) * STAGE) + half * H + l31;
         const float4* xq = reinterpret_cast<const float4*>(smem + (st & 1) * STAGE + TK * H) + half * TR + wave * 32 + l31;
@@ -167,6 +160,8 @@ __global__ void __launch_bounds__(256) tdf_pair_kernel(TdfArgs p) {
                 a = an;
             }
         }
+        if (st + 1 < n1) tdf_commit_x(nbuf + TK * H, tid, xs);
+        dma_wait();
     }
     // ---- hand-over: bias + BatchNorm (the 32 rows of a wave share a channel: rows_per_ch % 32 == 0) + ReLU, in registers
     const int ch = (int)(((r0 + wave * 32) / p.rows_per_ch) % p.n_ch);
@@ -192,10 +187,7 @@ __global__ void __launch_bounds__(256) tdf_pair_kernel(TdfArgs p) {
     for (int fb = 0; fb < n2; ++fb) {
         const int st = n1 + fb;
         lds_barrier();
-        if (fb + 1 < n2) {
-            tdf_commit2<NH>(smem + ((st + 1) & 1) * STAGE, tid, wv);
-            if (fb + 2 < n2) tdf_load2<NH>(p, tid, fb + 2, wv);
-        }
+        if (fb + 1 < n2) tdf_dma_slab(p.w2p + (long)(fb + 1) * W2Q * 4, smem + ((st + 1) & 1) * STAGE, W2Q, tid);
         // residual x[row][32 fb + 8 q + 4 half .. + 3]: requested before the MFMAs, consumed behind them
         float4 rx[4];
 #pragma unroll
@@ -232,6 +224,7 @@ __global__ void __launch_bounds__(256) tdf_pair_kernel(TdfArgs p) {
                 *reinterpret_cast<float4*>(orow + f) = make_float4(e0, e1, e2, e3);
             }
         }
+        dma_wait();
     }
 }
 
@@ -252,18 +245,18 @@ extern "C" int aicg_tdf_pair_supported(int F, int H, int rows_per_ch) {
     return (H % 32 == 0 && (nh == 2 || nh == 3 || nh == 4 || nh == 6 || nh == 8 || nh == 12) && F % 32 == 0 && rows_per_ch % 32 == 0) ? 1 : 0;
 }
 
-extern "C" int aicg_tdf_pair(const float* x, const float* w1_packed, const float* b1, const float* s1, const float* t1, const float* w2,
+extern "C" int aicg_tdf_pair(const float* x, const float* w1_packed, const float* b1, const float* s1, const float* t1, const float* w2_packed,
                              const float* b2, const float* s2, const float* t2, float* out, int64_t R, int F, int H, int rows_per_ch,
                              int n_ch, void* stream) {
-    if (!x || !w1_packed || !w2 || !out) return fail(AICG_E_ARG, "aicg_tdf_pair: null pointer");
+    if (!x || !w1_packed || !w2_packed || !out) return fail(AICG_E_ARG, "aicg_tdf_pair: null pointer");
     if ((s1 != nullptr) != (t1 != nullptr) || (s2 != nullptr) != (t2 != nullptr)) return fail(AICG_E_ARG, "aicg_tdf_pair: scale without shift");
     if (!aicg_tdf_pair_supported(F, H, rows_per_ch) || n_ch < 1)
         return fail(AICG_E_SHAPE, "aicg_tdf_pair: needs H in 32 x {2,3,4,6,8,12}, F %% 32 == 0, rows_per_ch %% 32 == 0 (F %d, H %d, rows %d)", F, H, rows_per_ch);
     auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-    if (!al(x) || !al(w1_packed) || !al(w2) || !al(out) || (b1 && !al(b1)) || (b2 && !al(b2)))
+    if (!al(x) || !al(w1_packed) || !al(w2_packed) || !al(out) || (b1 && !al(b1)) || (b2 && !al(b2)))
         return fail(AICG_E_ARG, "aicg_tdf_pair: operands must be 16-byte aligned");
     if (R <= 0) return AICG_OK;
-    TdfArgs p{x, w1_packed, b1, s1, t1, w2, b2, s2, t2, out, (long)R, F, H, rows_per_ch, n_ch};
+    TdfArgs p{x, w1_packed, b1, s1, t1, w2_packed, b2, s2, t2, out, (long)R, F, H, rows_per_ch, n_ch};
     hipStream_t st = (hipStream_t)stream;
     switch (H / 32) {
         case 2: return launch_tdf<2>(p, st);

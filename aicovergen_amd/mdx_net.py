@@ -46,7 +46,7 @@ class _TfcTdf:
         self.b2 = sd[name + ".tdf.3.bias"].float().contiguous().to(dev)
         self.s1, self.t1 = (z.contiguous().to(dev) for z in _bn_affine(sd, name + ".tdf.1"))
         self.s2, self.t2 = (z.contiguous().to(dev) for z in _bn_affine(sd, name + ".tdf.4"))
-        self.w1p = None    # W1 in aicg_tdf_pair's packed order, made on first use for the geometries the fused kernel covers
+        self.w1p = self.w2p = None    # aicg_tdf_pair's packed weight images, made on first use for the geometries the fused kernel covers
 
     def __call__(self, x):
         for pc in self.convs:
@@ -55,8 +55,8 @@ class _TfcTdf:
         if not ops.split_precision and x.shape[2] % 32 == 0 and ops.tdf_pair_supported(f, h, x.shape[2]):
             # x + tdf(x) in one launch: the f / bn intermediate never leaves the register file (csrc/tdf_pair.hip)
             if self.w1p is None:
-                self.w1p = ops.pack_tdf_w1(self.w1)
-            return ops.tdf_pair(x, self.w1p, self.b1, self.s1, self.t1, self.w2, self.b2, self.s2, self.t2)
+                self.w1p, self.w2p = ops.pack_tdf_w1(self.w1), ops.pack_tdf_w2(self.w2)
+            return ops.tdf_pair(x, self.w1p, self.b1, self.s1, self.t1, self.w2p, self.b2, self.s2, self.t2)
         t = ops.linear_last(x, self.w1, self.b1, self.s1, self.t1, act=ops.ACT_RELU)
         return ops.linear_last(t, self.w2, self.b2, self.s2, self.t2, act=ops.ACT_RELU, res=x)  # x + tdf(x)
 

@@ -660,20 +660,34 @@ def pack_tdf_w1(w1):
     return w1.detach().float().t().reshape(f // 8, 4, 2, h).permute(0, 2, 3, 1).contiguous()
 
 
+def pack_tdf_w2(w2):
+    """(F, H) -> [F / 32] slabs of 32 rows x (H + 4) floats, each slab zero-padded to a multiple of 256 floats (aicg_tdf_pair's
+    w2_packed: the LDS image of a stage, row padding included, so that a stage is one contiguous HBM -> LDS DMA)."""
+    f, h = w2.shape
+    assert f % 32 == 0
+    slab = (32 * (h + 4) + 255) // 256 * 256
+    out = torch.zeros((f // 32, slab), dtype=torch.float32, device=w2.device)
+    rows = torch.zeros((f // 32, 32, h + 4), dtype=torch.float32, device=w2.device)
+    rows[:, :, :h] = w2.detach().float().reshape(f // 32, 32, h)
+    out[:, : 32 * (h + 4)] = rows.reshape(f // 32, -1)
+    return out.contiguous()
+
+
 def tdf_pair_supported(f, h, rows_per_ch):
     return bool(_lib.get().aicg_tdf_pair_supported(int(f), int(h), int(rows_per_ch)))
 
 
-def tdf_pair(x, w1p, b1, s1, t1, w2, b2, s2, t2, out=None):
-    """x + relu(bn2(relu(bn1(x W1^T + b1)) W2^T + b2)) over the last axis of a contiguous (B, C, T, F) map, one launch."""
-    assert x.is_contiguous() and x.dim() == 4 and w2.is_contiguous() and w1p.is_contiguous()
+def tdf_pair(x, w1p, b1, s1, t1, w2p, b2, s2, t2, out=None):
+    """x + relu(bn2(relu(bn1(x W1^T + b1)) W2^T + b2)) over the last axis of a contiguous (B, C, T, F) map, one launch.
+    w1p = pack_tdf_w1(W1), w2p = pack_tdf_w2(W2)."""
+    assert x.is_contiguous() and x.dim() == 4 and w2p.is_contiguous() and w1p.is_contiguous()
     b, c, t, f = x.shape
-    h = w2.shape[1]
-    assert w2.shape[0] == f and w1p.numel() == f * h
+    h = w1p.numel() // f
+    assert w1p.numel() == f * h and w2p.shape[0] == f // 32
     if out is None:
         out = torch.empty_like(x)
-    _check(x, w1p, b1, s1, t1, w2, b2, s2, t2, out)
-    _call("aicg_tdf_pair", _ptr(x), _ptr(w1p), _ptr(b1), _ptr(s1), _ptr(t1), _ptr(w2), _ptr(b2), _ptr(s2), _ptr(t2), _ptr(out),
+    _check(x, w1p, b1, s1, t1, w2p, b2, s2, t2, out)
+    _call("aicg_tdf_pair", _ptr(x), _ptr(w1p), _ptr(b1), _ptr(s1), _ptr(t1), _ptr(w2p), _ptr(b2), _ptr(s2), _ptr(t2), _ptr(out),
           b * c * t, f, h, t, c, _stream(x))
     return out
 
@@ -993,8 +1007,8 @@ def dense_nt(x, weight, bias=None, act=ACT_NONE):
 _linear_last_raw = linear_last
 _gemm_work = lambda a, k, r: (2.0 * r.numel() * a[1].shape[1], 4.0 * _numel(a[0], a[1], r, k.get("res")))
 linear_last = _staged("tdf_gemm_nt", linear_last, _gemm_work)
-tdf_pair = _staged("tdf_pair", tdf_pair, lambda a, k, r: (4.0 * a[0].numel() * a[5].shape[1],      # 2 GEMMs of R x F x H
-                                                          4.0 * _numel(a[0], a[0], r, a[1], a[5])))  # x twice (operand + residual), out
+tdf_pair = _staged("tdf_pair", tdf_pair, lambda a, k, r: (4.0 * a[0].numel() * (a[1].numel() // a[0].shape[3]),   # 2 GEMMs of R x F x H
+                                                          4.0 * _numel(a[0], r, a[1], a[1])))    # x once (re-read for the residual from L2), out, weights
 dense_nt = _staged("dense_gemm_nt", dense_nt, _gemm_work)
 attention = _staged("attention", attention, lambda a, k, r: (4.0 * a[0].numel() * a[0].shape[1],      # 4 T^2 D per head
                                                              4.0 * _numel(a[0], a[1], a[2], r)))

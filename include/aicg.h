@@ -241,12 +241,13 @@ int aicg_gemm_nt_split(const float* a, const float* w, const float* bias, const 
 
 /* The whole TDF block of the MDX-Net U-Net in one launch (graph executed at src/mdx.py:74-77,193):
  *   out = x + relu(bn2(relu(bn1(x W1^T + b1)) W2^T + b2)),  x / out (R, F) contiguous rows of a (B, C, T, F) map, W1 (H, F), W2 (F, H).
- * w1_packed: W1 re-laid-out as [F / 8][2][H][4] with element e of quad (g, par, h) = W1[h][8 g + 2 e + par]; w2 row-major;
+ * w1_packed: W1 re-laid-out as [F / 8][2][H][4] with element e of quad (g, par, h) = W1[h][8 g + 2 e + par]; w2_packed: W2 as
+ * F / 32 slabs of 32 rows x (H + 4) floats, each slab zero-padded to a multiple of 256 floats (the LDS images of the stages);
  * s*, t*: eval BatchNorm2d scale / shift of the channel a row belongs to, ch = (row / rows_per_ch) % n_ch (NULL: none).
  * The (R, H) intermediate stays in the accumulator registers (csrc/tdf_pair.hip).  aicg_tdf_pair_supported returns 1 for the
  * geometries instantiated (H = 32 x {2, 3, 4, 6, 8, 12}, F % 32 == 0, rows_per_ch % 32 == 0); others take two aicg_gemm_nt calls. */
 int aicg_tdf_pair_supported(int F, int H, int rows_per_ch);
-int aicg_tdf_pair(const float* x, const float* w1_packed, const float* b1, const float* s1, const float* t1, const float* w2,
+int aicg_tdf_pair(const float* x, const float* w1_packed, const float* b1, const float* s1, const float* t1, const float* w2_packed,
                   const float* b2, const float* s2, const float* t2, float* out, int64_t R, int F, int H, int rows_per_ch,
                   int n_ch, void* stream);
 /* out = a * b elementwise (U-Net skip connection of the TFC-TDF net: x *= ds_outputs[-i-1]) */

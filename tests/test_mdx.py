@@ -138,3 +138,26 @@ def test_separation_matches_reference_golden(dev):
         assert np.abs(inv - g["inv_" + tag]).max() < 1e-4 * scale
     mix, pad, trim = sess.pad_wave(g["pad_in"])
     assert [pad, trim] == g["pad_trim"].tolist() and np.array_equal(mix.cpu().numpy(), g["pad_windows"])
+
+
+@pytest.mark.parametrize("f,h,t,c,b", [(256, 64, 32, 3, 2), (768, 96, 64, 2, 1), (3072, 384, 32, 5, 1), (512, 128, 32, 2, 3)])
+def test_tdf_pair_fused_kernel(dev, f, h, t, c, b):
+    """aicg_tdf_pair: x + relu(bn2(relu(bn1(x W1^T + b1)) W2^T + b2)) in one launch (the f / bn intermediate stays in the
+    accumulator registers) against torch and against the two-GEMM path it replaces; R = b c t rows incl. a ragged last 128-row
+    workgroup, 2 / 3 / 4 / 12 accumulator tiles per wave."""
+    from aicovergen_amd import ops
+    torch.manual_seed(f + h)
+    x = torch.randn(b, c, t, f)
+    w1, b1 = torch.randn(h, f) / f ** 0.5, torch.randn(h) * 0.1
+    w2, b2 = torch.randn(f, h) / h ** 0.5, torch.randn(f) * 0.1
+    s1, t1, s2, t2 = torch.rand(c) + 0.5, torch.randn(c) * 0.1, torch.rand(c) + 0.5, torch.randn(c) * 0.1
+    bn = lambda v, s, sh: v * s.view(1, c, 1, 1) + sh.view(1, c, 1, 1)
+    ref = x + torch.relu(bn(torch.relu(bn(x @ w1.t() + b1, s1, t1)) @ w2.t() + b2, s2, t2))
+    assert ops.tdf_pair_supported(f, h, t)
+    d = lambda v: dev.t(v.contiguous())
+    got = ops.tdf_pair(d(x), d(ops.pack_tdf_w1(w1)), d(b1), d(s1), d(t1), d(ops.pack_tdf_w2(w2)), d(b2), d(s2), d(t2))
+    assert rel_rms(got, ref) < 2e-6
+    two = ops.linear_last(ops.linear_last(d(x), d(w1), d(b1), d(s1), d(t1), act=ops.ACT_RELU), d(w2), d(b2), d(s2), d(t2),
+                          act=ops.ACT_RELU, res=d(x))
+    assert rel_rms(got, two) < 2e-6
+    assert not ops.tdf_pair_supported(96, 12, 8) and not ops.tdf_pair_supported(256, 64, 48)
