@@ -65,7 +65,22 @@ __device__ __forceinline__ void lds_dma16(const float* g, float* lds_wave_base, 
     *reinterpret_cast<float4*>(lds_wave_base + 4 * lane) = *reinterpret_cast<const float4*>(g);
 #else
     (void)lane;
-    __builtin_amdgcn_global_load_lds(g, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+    // Issued through inline asm ON PURPOSE.  With __builtin_amdgcn_global_load_lds the compiler knows the instruction writes LDS, cannot
+    // prove that the destination (the OTHER stage buffer) does not alias the fragment reads that follow, and puts an
+    // `s_waitcnt vmcnt(0)` in front of the first ds_read: every stage then exposes a full HBM round trip before its MFMAs (measured r3:
+    // 10.2 ms for the level-0 block, of which 3.9 ms remained with every MFMA removed).  The asm form is invisible to that pass; the
+    // hand-written dma_wait() at the end of the stage is what orders it.  M0 carries the wave-uniform LDS base and is restored.
+    const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(g), "s"(lds)
+                 : "memory");
+#endif
+}
+__device__ __forceinline__ void sched_fence() {
+#ifndef AICG_EMULATED
+    __builtin_amdgcn_sched_barrier(0);
 #endif
 }
 // every DMA this wave issued has landed (the LDS-only barrier behind it publishes the stage)
@@ -89,13 +104,14 @@ __device__ __forceinline__ void tdf_load_x(const TdfArgs& p, int tid, long r0, i
     const long r = r0 + row;
     const bool ok = r < p.R;
     const float4* xr = reinterpret_cast<const float4*>(p.x + (ok ? r : 0) * p.F + (long)st * TK + 8 * gg);
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 t0 = xr[0], t1 = xr[1], t2 = xr[4], t3 = xr[5];   // + 16 floats: group gg + 2
-    v.a0 = ok ? t0 : z; v.a1 = ok ? t1 : z; v.b0 = ok ? t2 : z; v.b1 = ok ? t3 : z;
+    // raw values only: anything that CONSUMES them here (even the zero select of the rows past R) would be scheduled right behind the
+    // loads and wait for them in front of the stage's MFMAs -- tdf_commit_x masks
+    v.a0 = xr[0]; v.a1 = xr[1]; v.b0 = xr[4]; v.b1 = xr[5];   // + 16 floats: group gg + 2
 }
 
-__device__ __forceinline__ void tdf_commit_x(float* xbuf, int tid, const XStage& v) {
+__device__ __forceinline__ void tdf_commit_x(const TdfArgs& p, float* xbuf, int tid, long r0, XStage v) {
     const int row = tid & (TR - 1), gg = tid >> 7;
+    if (r0 + row >= p.R) v.a0 = v.a1 = v.b0 = v.b1 = make_float4(0.f, 0.f, 0.f, 0.f);   // rows past the end read row 0: zero them
     float4* xdst = reinterpret_cast<float4*>(xbuf);
     // k = 8 g + 2 j + par: parity 0 takes elements 0, 2, 4, 6 of the 8 loaded values, parity 1 the odd ones
     xdst[(gg * 2) * TR + row] = make_float4(v.a0.x, v.a0.z, v.a1.x, v.a1.z);
@@ -132,7 +148,7 @@ __global__ void __launch_bounds__(256) tdf_pair_kernel(TdfArgs p) {
     XStage xs;
     tdf_dma_slab(p.w1p, smem, W1Q, tid);
     tdf_load_x(p, tid, r0, 0, xs);
-    tdf_commit_x(smem + TK * H, tid, xs);
+    tdf_commit_x(p, smem + TK * H, tid, r0, xs);
     dma_wait();
     // ---- phase 1: acc[i] = (x W1^T)^T tile i: rows h = 32 i .. 32 i + 31, column = this lane's row
     for (int st = 0; st < n1; ++st) {
@@ -160,7 +176,10 @@ __global__ void __launch_bounds__(256) tdf_pair_kernel(TdfArgs p) {
                 a = an;
             }
         }
-        if (st + 1 < n1) tdf_commit_x(nbuf + TK * H, tid, xs);
+        // nothing that consumes the x loads may be scheduled above the MFMAs (without the fence hipcc hoists the parity shuffles of
+        // tdf_commit_x to the top of the stage and waits for the loads -- and the DMA queued before them -- in front of the MFMAs)
+        sched_fence();
+        if (st + 1 < n1) tdf_commit_x(p, nbuf + TK * H, tid, r0, xs);
         dma_wait();
     }
     // ---- hand-over: bias + BatchNorm (the 32 rows of a wave share a channel: rows_per_ch % 32 == 0) + ReLU, in registers
@@ -187,12 +206,16 @@ __global__ void __launch_bounds__(256) tdf_pair_kernel(TdfArgs p) {
     for (int fb = 0; fb < n2; ++fb) {
         const int st = n1 + fb;
         lds_barrier();
-        if (fb + 1 < n2) tdf_dma_slab(p.w2p + (long)(fb + 1) * W2Q * 4, smem + ((st + 1) & 1) * STAGE, W2Q, tid);
         // residual x[row][32 fb + 8 q + 4 half .. + 3]: requested before the MFMAs, consumed behind them
-        float4 rx[4];
+        float4 rx[4], bq4[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < 4; ++q) {
             rx[q] = row_ok ? *reinterpret_cast<const float4*>(xrow + 32 * fb + 8 * q + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bq4[q] = p.b2 ? *reinterpret_cast<const float4*>(p.b2 + 32 * fb + 8 * q + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        // the DMA goes out BEHIND these loads: hipcc guards the re-use of the previous stage's store-data registers with a vmcnt(0),
+        // which must only meet stores issued a whole stage ago, not a DMA issued a moment ago (vmcnt retires in order)
+        if (fb + 1 < n2) tdf_dma_slab(p.w2p + (long)(fb + 1) * W2Q * 4, smem + ((st + 1) & 1) * STAGE, W2Q, tid);
         const float4* w2q = reinterpret_cast<const float4*>(smem + (st & 1) * STAGE + l31 * W2LD) + half;   // row f = l31 of the slab
         f32x16 o;
 #pragma unroll
@@ -210,11 +233,12 @@ __global__ void __launch_bounds__(256) tdf_pair_kernel(TdfArgs p) {
                 o = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, acc[i][4 * q + 3], o, 0, 0, 0);
                 a = an;
             }
+        dma_wait();   // the next slab's DMA (issued a whole stage ago) and this stage's loads; the stores below drain under the next stage
         if (row_ok) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int f = 32 * fb + 8 * q + 4 * half;
-                const float4 bq = p.b2 ? *reinterpret_cast<const float4*>(p.b2 + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 bq = bq4[q];
                 float e0 = (o[4 * q] + bq.x) * sc2 + sh2, e1 = (o[4 * q + 1] + bq.y) * sc2 + sh2;
                 float e2 = (o[4 * q + 2] + bq.z) * sc2 + sh2, e3 = (o[4 * q + 3] + bq.w) * sc2 + sh2;
                 e0 = (e0 > 0.f ? e0 : 0.f) + rx[q].x;
@@ -224,7 +248,6 @@ __global__ void __launch_bounds__(256) tdf_pair_kernel(TdfArgs p) {
                 *reinterpret_cast<float4*>(orow + f) = make_float4(e0, e1, e2, e3);
             }
         }
-        dma_wait();
     }
 }
 

@@ -96,6 +96,21 @@ def assert_bins_agree(coarse, f0, want_coarse, want_f0, want_salience, max_rate=
         assert abs(int(coarse[t]) - int(want_coarse[t])) <= 1 or m < 1e-3
 
 
+def test_cut_points_do_not_depend_on_the_filter_implementation(dev, monkeypatch):
+    """plan() high-passes on the device (block-parallel filtfilt, ~5e-8 of the peak from scipy's sequential one) and then searches
+    the quietest sample bit-exactly: the cut points -- and with them every chunk boundary -- must equal the ones the host filter
+    gives.  CPU: 9 s with 1 s windows; GPU: the bench's 240 s track with main.py's preset."""
+    nets = weights.small_model_set(3)
+    x = (3, 10, 60, 65) if dev.big else (1, 1, 1, 2)
+    vc, _, _, _ = build(dev, nets, x)
+    audio = vocal_like(240.0 if dev.big else 9.0, 16000, 1234)
+    _, pad_dev, ts_dev, p_dev = vc.plan(audio)
+    monkeypatch.setenv("AICG_FILTFILT", "host")
+    _, pad_host, ts_host, p_host = vc.plan(audio)
+    assert len(ts_dev) >= 3 and [int(t) for t in ts_dev] == [int(t) for t in ts_host] and p_dev == p_host
+    assert float((pad_dev - pad_host).abs().max()) < 1e-6 * float(pad_host.abs().max())
+
+
 def test_change_rms_matches_oracle():
     rng = np.random.default_rng(0)
     a = rng.standard_normal(16000 * 2).astype(np.float64) * 0.1
