@@ -19,7 +19,7 @@ def _bench():
     return m
 
 
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(ROOT, "profiles", "r02_bench_*.json"))))
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[23]_bench_*.json"))))
 def test_committed_bench_lines_follow_the_contract(path):
     lines = [ln for ln in open(path).read().splitlines() if ln.strip()]
     assert len(lines) == 1                                   # ONE JSON line on stdout
@@ -47,8 +47,11 @@ def test_committed_bench_lines_follow_the_contract(path):
 
 
 def test_default_line_has_the_cpu_baseline():
-    d = json.loads(open(os.path.join(ROOT, "profiles", "r02_bench_c3_default.json")).read())
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r03_bench_c3_default.json")).read())
     assert d["config"]["config_id"] == "C3" and d["dtype"] == "f32" and "cpu_baseline" in d and d["roofline"]["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["ref_cpu_seconds"] > 0 and c["ref_threads"] >= 1     # the reference's own C1 time rides along
+    assert d["config"]["profiled_step_ms"] > 0 and len(d["config"]["per_rank_seconds_per_step"]) == 1
 
 
 def test_stage_table_and_traffic_helpers():
@@ -62,4 +65,4 @@ def test_stage_table_and_traffic_helpers():
     assert rows[1]["unit"] == "TFLOP/s" and abs(rows[1]["achieved"] - 100.0) < 1e-9
     assert rows[2]["bound"] == "hbm" and abs(rows[2]["achieved"] - 350.0) < 1e-9
     t = b.pmc_traffic_per_launch()
-    assert t is not None and t["fetch_x2"] > t["raw"] > 0 and t["source"].startswith("profiles/r02")
+    assert t is not None and t["fetch_x2"] > t["raw"] > 0 and t["source"].startswith("profiles/r03")
