@@ -217,10 +217,11 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& bo
     const long total = (long)grid.x * grid.y * grid.z;
     if (total <= 0) return;
     unsigned hw = std::thread::hardware_concurrency();
-    if (hw < 4) hw = 4;  // kernels whose workgroups wait for each other (2-workgroup GRU) need their partners running concurrently,
-                         // even if that means time-sharing one core
     const char* env = getenv("AICG_EMU_THREADS");
     if (env) hw = (unsigned)atoi(env);
+    if (hw < 4) hw = 4;  // kernels whose workgroups wait for each other (the 4-workgroup GRU: a quad is contiguous in dispatch order)
+                         // need their partners running concurrently, even if that means time-sharing one core -- also when
+                         // AICG_EMU_THREADS asks for fewer
     const long nthreads = total < (long)hw ? total : (long)hw;
     std::atomic<long> next{0};
     auto worker = [&]() {
