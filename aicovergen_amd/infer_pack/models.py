@@ -315,12 +315,29 @@ class _SynthesizerBase:
             phone_ct = phone[0].t().contiguous().unsqueeze(0)  # (1, phone_dim, T)  layout plumbing
         else:
             T = phone_ct.shape[2]
+        front = self.infer_front(phone_ct, pitch, sid, noise_z)
+        return self.infer_back(front, nsff0, noise_src, max_len)
+
+    def infer_front(self, phone_ct, pitch, sid, noise_z=None):
+        """First half of infer(): speaker embedding, text encoder, prior sample, reverse flow -> state for infer_back.  A few
+        hundred short launches over T frames (they leave most of the chip idle): VC.pipeline queues the next chunk's front on a
+        second stream underneath the current chunk's vocoder."""
+        P = self._prepare()
+        dev = self.device
+        T = phone_ct.shape[2]
         g = P["emb_g"][sid.to(dev).reshape(-1)[:1]].unsqueeze(-1).contiguous()  # (1, gin, 1)
         stats = self._enc_p(P, phone_ct, None if pitch is None else pitch.to(dev))
         if noise_z is None:
             noise_z = torch.randn((1, self.inter_channels, T), device=dev)  # reference: models.py:748
         z_p = ops.prior_sample(stats, noise_z.to(dev).float().contiguous(), 0.66666)
         z = self._flow_reverse(P, z_p.clone(), g)
+        return {"z": z, "z_p": z_p, "stats": stats, "g": g, "T": T}
+
+    def infer_back(self, front, nsff0=None, noise_src=None, max_len=None):
+        """Second half of infer(): the (NSF-)HiFiGAN vocoder on the flow's output -> (o, x_mask, (z, z_p, m_p, logs_p))."""
+        P = self._prepare()
+        dev = self.device
+        z, z_p, stats, g, T = front["z"], front["z_p"], front["stats"], front["g"], front["T"]
         zz = z if max_len is None else z[:, :, :max_len].contiguous()
         o = self._decoder(P, zz, None if nsff0 is None else nsff0.to(dev).float(), g, noise_src)
         x_mask = torch.ones((1, 1, T), dtype=torch.float32, device=dev)

@@ -263,6 +263,17 @@ class VC(object):
 
     def _vc_synth(self, net_g, sid, n_samples, feats, feats0, pitch, pitchf, protect, noise):
         """Features (+ pitch) of one chunk -> synthesizer output (1, 1, T) on the device, reference :433-466."""
+        return self._vc_synth_back(net_g, self._vc_synth_front(net_g, sid, n_samples, feats, feats0, pitch, pitchf, protect, noise))
+
+    def _vc_synth_back(self, net_g, st):
+        """Vocoder half of a chunk's synthesis (state from _vc_synth_front)."""
+        if "front" not in st:
+            return st["o"]
+        return net_g.infer_back(st["front"], st["pitchf"], st["ns"])[0]
+
+    def _vc_synth_front(self, net_g, sid, n_samples, feats, feats0, pitch, pitchf, protect, noise):
+        """Encoder half of a chunk's synthesis: nearest x2 upsample + protect blend, text encoder, prior sample, reverse flow.
+        Synthesizers without the front / back split (any object with the reference's `infer`) run whole here."""
         p_len = n_samples // self.window
         if 2 * feats.shape[1] < p_len:
             p_len = 2 * feats.shape[1]
@@ -274,10 +285,12 @@ class VC(object):
         phone_ct = ops.feats_prepare(feats[0], p_len, feats0[0] if use_protect else None,
                                      pitchf[0].float() if use_protect else None, protect)
         nz, ns = noise if noise is not None else (None, None)
+        if hasattr(net_g, "infer_front"):
+            return {"front": net_g.infer_front(phone_ct, pitch, sid, nz), "pitchf": pitchf, "ns": ns}
         lens = torch.tensor([p_len], device=self.device).long()
         if pitch is not None and pitchf is not None:
-            return net_g.infer(None, lens, pitch, pitchf, sid, noise_z=nz, noise_src=ns, phone_ct=phone_ct)[0]
-        return net_g.infer(None, lens, sid, noise_z=nz, noise_src=ns, phone_ct=phone_ct)[0]
+            return {"o": net_g.infer(None, lens, pitch, pitchf, sid, noise_z=nz, noise_src=ns, phone_ct=phone_ct)[0]}
+        return {"o": net_g.infer(None, lens, sid, noise_z=nz, noise_src=ns, phone_ct=phone_ct)[0]}
 
     def _sync(self):
         return torch.cuda.is_available() and str(self.device).startswith("cuda")
@@ -438,22 +451,61 @@ class VC(object):
             t2 = ttime()
             times[1] += t2 - t1
         pieces = {}
-        for ci in mine:
+
+        def chunk_pitch(ci):
             s, e = bounds[ci]
-            last = ci == len(bounds) - 1
-            if if_f0 == 1:
-                pe = None if last else (e - self.window) // self.window
-                pc, pcf = pitch[:, s // self.window: pe], pitchf[:, s // self.window: pe]
-            else:
-                pc = pcf = None
-            noise = noise_fn(ci, s, e) if noise_fn is not None else None
-            if overlap:
+            if if_f0 != 1:
+                return None, None
+            pe = None if ci == len(bounds) - 1 else (e - self.window) // self.window
+            return pitch[:, s // self.window: pe], pitchf[:, s // self.window: pe]
+
+        # Overlapped schedule: the encoder half of chunk i + 1 (text encoder + flow: a few hundred short launches that leave most
+        # CUs idle) is queued on a second stream underneath the vocoder of chunk i.  AICG_OVERLAP_SYNTH=0: one stream.
+        two_streams = overlap and hasattr(net_g, "infer_front") and os.environ.get("AICG_OVERLAP_SYNTH", "1") != "0"
+        fronts = {}
+        if two_streams:
+            main = torch.cuda.current_stream(self.device)
+            enc = getattr(self, "_enc_stream", None)
+            if enc is None:
+                enc = self._enc_stream = torch.cuda.Stream(device=self.device)
+            enc.wait_stream(main)          # features, pitch tracks, sid: everything the fronts read exists on `main` by now
+
+            def queue_front(ci):
+                s, e = bounds[ci]
+                pc, pcf = chunk_pitch(ci)
+                feats, feats0 = feats_of.pop(ci)
+                with torch.cuda.stream(enc):
+                    noise = noise_fn(ci, s, e) if noise_fn is not None else None
+                    st = self._vc_synth_front(net_g, sid, e - s, feats, feats0, pc, pcf, protect, noise)
+                    ev = torch.cuda.Event()
+                    ev.record(enc)
+                # the inputs stay referenced until the chunk's synchronize below: nothing is recycled under the other stream
+                fronts[ci] = (st, ev, (feats, feats0, pc, pcf, noise))
+
+            if mine:
+                queue_front(mine[0])
+        for k, ci in enumerate(mine):
+            s, e = bounds[ci]
+            pc, pcf = chunk_pitch(ci)
+            if two_streams:
+                ts0 = ttime()
+                if k + 1 < len(mine):
+                    queue_front(mine[k + 1])
+                st, ev, keep = fronts.pop(ci)
+                main.wait_event(ev)
+                out = self._vc_synth_back(net_g, st)[0, 0]
+                torch.cuda.synchronize()
+                del st, keep
+                times[2] += ttime() - ts0
+            elif overlap:
+                noise = noise_fn(ci, s, e) if noise_fn is not None else None
                 ts0 = ttime()
                 feats, feats0 = feats_of.pop(ci)
                 out = self._vc_synth(net_g, sid, e - s, feats, feats0, pc, pcf, protect, noise)[0, 0]
                 torch.cuda.synchronize()
                 times[2] += ttime() - ts0
             else:
+                noise = noise_fn(ci, s, e) if noise_fn is not None else None
                 out = self.vc(model, net_g, sid, audio_pad[s:e], pc, pcf, times, index, big_npy, index_rate, version, protect,
                               noise=noise, keep_on_device=True)
             pieces[ci] = out[self.t_pad_tgt: -self.t_pad_tgt]
