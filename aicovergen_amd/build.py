@@ -55,7 +55,7 @@ def _build(force, verbose, dev):
     hipcc = _hipcc()
     os.makedirs(OBJ_DIR, exist_ok=True)
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-constant-logical-operand"] + (["-DAICG_DEV_SWITCHES"] if dev else [])
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-constant-logical-operand"] + (["-DAICG_DEV_SWITCHES", "-DAICG_CONV_ABLATION"] if dev else [])
     jobs = []
     objs = []
     for src in sources():

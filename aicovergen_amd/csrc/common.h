@@ -88,6 +88,10 @@ __device__ __forceinline__ float4 buf_load_f32x4(const BufRsrc& r, unsigned voff
     if ((unsigned long)voff + 16 > r.num_records) return make_float4(0.f, 0.f, 0.f, 0.f);
     return *reinterpret_cast<const float4*>(r.base + voff);
 }
+__device__ __forceinline__ float buf_load_f32_s(const BufRsrc& r, unsigned voff, unsigned soff) {
+    if ((unsigned long)voff + 4 > r.num_records) return 0.f;   // like the hardware: the scalar offset is not range checked
+    return *reinterpret_cast<const float*>(r.base + voff + soff);
+}
 #else
 // The raw-buffer intrinsics are bound by name (the clang builtin __builtin_amdgcn_raw_buffer_load_b128 of ROCm 7.2 lowers to
 // a 32-bit load and splats it); the resource is the classic 4-dword descriptor {base[47:0], stride 0, num_records, flags}.
@@ -106,6 +110,11 @@ __device__ __forceinline__ BufRsrc make_buf(const void* base, unsigned num_bytes
     return r;
 }
 __device__ __forceinline__ float buf_load_f32(const BufRsrc& r, unsigned voff) { return llvm_amdgcn_raw_buffer_load_f32(r.d, (int)voff, 0, 0); }
+// voff + a wave-uniform byte offset in an SGPR: no VALU add per load.  The hardware range-checks voff alone (the scalar offset is
+// excluded), so the caller guarantees that base + voff + soff is inside the tensor whenever voff is in range.
+__device__ __forceinline__ float buf_load_f32_s(const BufRsrc& r, unsigned voff, unsigned soff) {
+    return llvm_amdgcn_raw_buffer_load_f32(r.d, (int)voff, (int)soff, 0);
+}
 __device__ __forceinline__ float4 buf_load_f32x4(const BufRsrc& r, unsigned voff) {
     const buf_f32x4 v = llvm_amdgcn_raw_buffer_load_v4f32(r.d, (int)voff, 0, 0);
     return make_float4(v.x, v.y, v.z, v.w);

@@ -1,6 +1,7 @@
 // aicg_conv_forward: geometry checks, tile choice and launch of the implicit-GEMM convolution family (conv_kernels.h), plus
 // the pointwise streaming kernel for 1x1 layers with <= 8 channels on one side.
 #include "conv_ws3s.h"
+#include "conv_ws3w.h"
 
 namespace aicg {
 
@@ -143,6 +144,34 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
     p.w_group_stride = (long)p.taps * p.Cin_pad * p.Mpad;
     p.w3 = d->packed_v3 ? w_packed + (long)p.groups * p.w_group_stride : nullptr;
     p.wsplit = d->packed_v3 && d->split ? w_packed + 2L * p.groups * p.w_group_stride : nullptr;
+
+    if (d->wino) {
+        // Winograd F(2, 3) along rows (conv_ws3w.h): w_packed is the image pair of the (Cout, Cin, 3, 4) kernel, 12 taps
+        if (p.KH != 3 || p.KW != 3 || p.sh != 1 || p.sw != 1 || p.dh != 1 || p.dw != 1 || p.ph != 1 || p.pw != 1 || pad_h_end != 1 ||
+            pad_w_end != 1 || p.groups != 1 || res || p.accumulate || p.shuffle || p.res_mul || p.pre_act != AICG_ACT_NONE ||
+            p.out_scale != 1.f || !d->packed_v3 || (p.act != AICG_ACT_NONE && p.act != AICG_ACT_RELU) || Ho != p.H || Wo != p.W)
+            return fail(AICG_E_ARG, "aicg_conv_forward: wino needs a plain 3x3 / stride 1 / padding 1 layer (bias + none|ReLU epilogue)");
+        AICG_SWITCH(wino_ablate, "AICG_CONV_ABLATE", 0);
+        p.dbg = wino_ablate;
+        p.taps = 12;
+        p.w_group_stride = (long)p.taps * p.Cin_pad * p.Mpad;
+        p.w3 = w_packed + p.w_group_stride;
+        // output-channel tile with the least padding (the larger on ties): 96 / 64 / 32 rows on the 32 x 32 x 2 MFMA, 48 on 16 x 16 x 4
+        const int M = p.Cout_g;
+        int bm = 32;
+        long best = 1L << 40;
+        const int cands[4] = {96, 64, 48, 32};
+        AICG_SWITCH(wino_bm, "AICG_WINO_BM", 0);
+        for (int i = 0; i < 4; ++i) {
+            const long padded = (long)idiv_up(M, cands[i]) * cands[i];
+            if (padded < best) { best = padded; bm = cands[i]; }
+        }
+        if (wino_bm) bm = (int)wino_bm;
+        hipStream_t wst = (hipStream_t)stream;
+        const int rc = bm == 96 ? run_ws3w_96(p, wst) : bm == 64 ? run_ws3w_64(p, wst) : bm == 48 ? run_ws3w_48(p, wst) : run_ws3w_32(p, wst);
+        if (rc == 1) return fail(AICG_E_SHAPE, "aicg_conv_forward: wino layer too large for the kernel's 32-bit offsets");
+        return rc;
+    }
 
     // pointwise streaming form: 1x1, unit stride, no padding, <= 8 channels on one side, float4-aligned rows
     {

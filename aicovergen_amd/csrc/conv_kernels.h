@@ -29,7 +29,7 @@
 
 namespace aicg {
 
-// Phase-ablation switches (AICG_CONV_ABLATE bits in ConvArgs::dbg) exist only in builds made with -DAICG_CONV_ABLATION
+// Phase-ablation switches (AICG_CONV_ABLATE bits in ConvArgs::dbg) exist only in builds made with -DAICG_CONV_ABLATION (build.py --dev)
 // (tools/): the shipped kernels carry no profiling branches in their hot loops.
 #ifdef AICG_CONV_ABLATION
 static constexpr bool kAblate = true;

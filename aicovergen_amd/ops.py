@@ -146,7 +146,7 @@ class ConvDesc(ctypes.Structure):
                 ("act_slope", ctypes.c_float), ("out_scale", ctypes.c_float), ("accumulate", ctypes.c_int32),
                 ("res_before_act", ctypes.c_int32), ("pad_h_end", ctypes.c_int32), ("pad_w_end", ctypes.c_int32),
                 ("shuffle", ctypes.c_int32), ("res_mul", ctypes.c_int32), ("packed_v3", ctypes.c_int32),
-                ("split", ctypes.c_int32)]
+                ("split", ctypes.c_int32), ("wino", ctypes.c_int32)]
 
 
 def conv_bkc(taps):
@@ -215,6 +215,19 @@ def pack_conv_weight(w, groups=1, split=False):
     return torch.cat(parts).contiguous()
 
 
+# Winograd F(2, 3) along rows for plain 3 x 3 layers (csrc/conv_ws3w.h): 12 instead of 18 MFMA contractions per output pair.  Layers
+# packed while this is set carry the transformed kernel next to the direct one; conv() takes it for large maps with a bias + none /
+# ReLU epilogue.  The f0 models (packed under fp32_layers()) never do: their goldens pin the direct summation order's bins.
+winograd = os.environ.get("AICG_WINOGRAD", "1") != "0"
+winograd_min_positions = 32768   # below this the 64-column tiles (4 or 8 rows) do not fill the chip (tests lower it)
+
+
+def winograd_kernel(w):
+    """(Cout, Cin, 3, 3) -> (Cout, Cin, 3, 4): G g along the last axis, G = [[1, 0, 0], [1/2, 1/2, 1/2], [1/2, -1/2, 1/2], [0, 0, 1]]."""
+    g0, g1, g2 = w[..., 0], w[..., 1], w[..., 2]
+    return torch.stack([g0, (g0 + g1 + g2) * 0.5, (g0 - g1 + g2) * 0.5, g2], -1).contiguous()
+
+
 class PackedConv:
     """A convolution layer ready for aicg_conv_forward: packed weights + geometry.  1-D layers use KH=1."""
 
@@ -236,6 +249,10 @@ class PackedConv:
         self.split = bool(split_precision)
         self.w = pack_conv_weight(weight.to(device), groups, self.split)
         self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
+        self.w_wino = None
+        if (winograd and not self.split and not _fp32_depth and (self.kh, self.kw) == (3, 3) and stride == (1, 1) and dilation == (1, 1)
+                and padding == (1, 1) and self.padding_end is None and groups == 1 and cin_g >= 8):
+            self.w_wino = pack_conv_weight(winograd_kernel(weight.detach().to(device=device, dtype=torch.float32)), 1, False)
 
     def out_hw(self, h, w):
         pe = self.padding if self.padding_end is None else self.padding_end
@@ -340,11 +357,16 @@ def conv(x, pc, res=None, out=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NON
     d.shuffle, d.res_mul = int(shuffle), 1 if res_mul else 0
     d.packed_v3 = 1
     d.split = 1 if getattr(pc, "split", False) else 0
+    # Winograd form: plain 3 x 3 layer, bias + none / ReLU epilogue, an even row length and enough output to fill the chip
+    wino = (getattr(pc, "w_wino", None) is not None and not is1d and res is None and not accumulate and pre_act == ACT_NONE
+            and out_scale == 1.0 and act in (ACT_NONE, ACT_RELU) and not shuffle and out_len is None and wo % 2 == 0
+            and n * ho * wo >= winograd_min_positions)
+    d.wino = 1 if wino else 0
     prof = conv_profile
     if prof is not None and x.is_cuda:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _call("aicg_conv_forward", ctypes.addressof(d), _ptr(x4), _ptr(pc.w), _ptr(b), _ptr(r4), _ptr(o4), _stream(x))
+    _call("aicg_conv_forward", ctypes.addressof(d), _ptr(x4), _ptr(pc.w_wino if wino else pc.w), _ptr(b), _ptr(r4), _ptr(o4), _stream(x))
     if prof is not None and x.is_cuda:
         e1.record()
         prof.events.append((e0, e1))

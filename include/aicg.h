@@ -119,6 +119,11 @@ typedef struct aicg_conv_desc {
                                      group and more than 16 output channels are then computed as hi*hi + hi*lo + lo*hi on the
                                      bf16 matrix pipe with fp32 accumulation (csrc/conv_ws3s.h: ~1e-5 relative to the fp32
                                      kernels); the other layers run the fp32 kernels unchanged */
+    int32_t wino;                 /* nonzero: w_packed holds the packed images of the (Cout, Cin, 3, 4) Winograd F(2, 3) kernel of a 3 x 3,
+                                     stride 1, dilation 1, padding 1, groups 1 layer -- U[.][.][kh][0..3] = (g0, (g0 + g1 + g2) / 2,
+                                     (g0 - g1 + g2) / 2, g2) of row kh -- and the layer runs csrc/conv_ws3w.h (12 instead of 18
+                                     contractions per output pair).  Needs packed_v3, no residual / accumulate / shuffle /
+                                     pre-activation, act none or ReLU, out_scale 1 */
 } aicg_conv_desc;
 
 int aicg_conv_bkc(int taps);

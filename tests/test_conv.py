@@ -95,6 +95,32 @@ def test_conv2d(dev, ci, co, kh, kw, s, p, H, W):
     assert rel_rms(y, F.relu(F.conv2d(x, w, b, stride=s, padding=p))) < 1e-5
 
 
+@pytest.mark.parametrize("n,ci,co,H,W,act", [(2, 8, 32, 4, 64, ops.ACT_RELU), (1, 20, 48, 7, 70, ops.ACT_RELU), (1, 16, 96, 5, 130, ops.ACT_NONE),
+                                              (1, 40, 144, 9, 66, ops.ACT_RELU), (1, 24, 64, 3, 2, ops.ACT_NONE), (2, 12, 48, 11, 70, ops.ACT_RELU),
+                                              (1, 16, 40, 8, 64, ops.ACT_NONE), (1, 8, 240, 3, 36, ops.ACT_RELU)])
+def test_conv2d_winograd_rows(dev, monkeypatch, n, ci, co, H, W, act):
+    """F(2, 3) along rows (csrc/conv_ws3w.h) on TFC-shaped layers: every tile height (32 / 64 / 96 output channels on the 32 x 32 x 2
+    MFMA, 48 -- also 144 = 3 x 48 and 240 = 5 x 48 -- on 16 x 16 x 4 with eight output rows a workgroup), ragged rows,
+    column tiles and channel chunks, output written into a channel slice.  Same products up to the exact 1/2 of G; the sums of the
+    transformed operands round differently from the direct form, hence 2e-6 rather than bit equality."""
+    monkeypatch.setattr(ops, "winograd_min_positions", 1)
+    torch.manual_seed(H * W + ci)
+    x = torch.randn(n, ci, H, W)
+    w = torch.randn(co, ci, 3, 3) * 0.1
+    b = torch.randn(co)
+    pc = ops.PackedConv(w, b, padding=1, device=dev.device)
+    assert pc.w_wino is not None
+    buf = dev.t(torch.full((n, co + 3, H, W), 7.0))
+    ops.conv(dev.t(x), pc, act=act, out=buf[:, 2:2 + co])
+    ref = F.conv2d(x, w, b, padding=1)
+    assert rel_rms(buf[:, 2:2 + co], F.relu(ref) if act == ops.ACT_RELU else ref) < 2e-6
+    assert (buf[:, :2] == 7).all() and (buf[:, 2 + co:] == 7).all()
+    # the epilogues the form does not cover stay on the direct kernels (residual here)
+    r = torch.randn(n, co, H, W)
+    y = ops.conv(dev.t(x), pc, res=dev.t(r))
+    assert rel_rms(y, ref + r) < 1e-5
+
+
 def test_conv_strided_views(dev):
     """Outputs may be channel slices of a larger buffer (decoder concat without a copy, rmvpe.py:166)."""
     torch.manual_seed(11)
