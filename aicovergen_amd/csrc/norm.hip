@@ -279,7 +279,9 @@ extern "C" int aicg_layernorm_ct(const float* x, const float* res, const float* 
     if (N == 0 || T == 0) return AICG_OK;
     if (C <= 1024) {
         hipStream_t st = (hipStream_t)stream;
-        const bool narrow = ldiv_up(T, 32) * N < 512;   // fewer than two workgroups per CU with 32-column blocks
+        // 32-column blocks (128-byte segments) from half a wave of workgroups per CU on: T = 13198 (HuBERT batched over a rank's chunks)
+        // 79 -> 46 us = 2.7 TB/s with the residual, (192, 6600) 13.8 -> 9.7 us; below that the 8-column form's 4x workgroups win
+        const bool narrow = ldiv_up(T, 32) * N < 128;
         dim3 grid((unsigned)ldiv_up(T, narrow ? 8 : 32), (unsigned)N);
 #define AICG_LN_LAUNCH(NV, CB) hipLaunchKernelGGL(HIP_KERNEL_NAME(layernorm_ct_reg_kernel<NV, CB>), grid, dim3(1024), 0, st, x, res, gamma, \
                                                   beta, out, C, (long)T, eps, (long)x_sn, (long)r_sn, (long)o_sn)

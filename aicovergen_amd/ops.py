@@ -280,6 +280,7 @@ class ConvProfile:
     def __init__(self):
         self.events = []
         self.flops = 0.0
+        self.flops_executed = 0.0  # what the matrix pipe was given: the Winograd form spends 12 instead of 18 MACs per output pair
         self.bytes = 0.0  # algorithmic HBM bytes: input + packed weights + output (+ residual / accumulate reads), each once
         self.launches = 0
         self.shapes = []  # per launch: (shape key, flops) -- by_shape() groups them
@@ -300,8 +301,9 @@ class ConvProfile:
     def summary(self):
         torch.cuda.synchronize()
         ms = sum(a.elapsed_time(b) for a, b in self.events)
-        return {"launches": self.launches, "flops": self.flops, "ms": ms, "bytes": self.bytes,
-                "tflops": (self.flops / (ms * 1e-3) / 1e12) if ms > 0 else 0.0}
+        return {"launches": self.launches, "flops": self.flops, "flops_executed": self.flops_executed, "ms": ms, "bytes": self.bytes,
+                "tflops": (self.flops / (ms * 1e-3) / 1e12) if ms > 0 else 0.0,
+                "tflops_executed": (self.flops_executed / (ms * 1e-3) / 1e12) if ms > 0 else 0.0}
 
 
 conv_profile = None
@@ -371,12 +373,13 @@ def conv(x, pc, res=None, out=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NON
         e1.record()
         prof.events.append((e0, e1))
         prof.flops += 2.0 * n * pc.cout * (pc.cin // pc.groups) * pc.kh * pc.kw * ho * wo
+        prof.flops_executed += 2.0 * n * pc.cout * (pc.cin // pc.groups) * pc.kh * pc.kw * ho * wo * (2.0 / 3.0 if wino else 1.0)
         prof.bytes += 4.0 * (n * c * h * w + pc.cout * (pc.cin // pc.groups) * pc.kh * pc.kw
                              + n * pc.cout * ho * wo * (1 + (r4 is not None) + bool(accumulate)))
         prof.launches += 1
         prof.shapes.append(("N%d C%d>%d %dx%d k%dx%d s%d,%d d%d,%d g%d%s%s%s" % (
             n, c, pc.cout, h, w, pc.kh, pc.kw, pc.stride[0], pc.stride[1], pc.dilation[0], pc.dilation[1], pc.groups,
-            " res" if r4 is not None else "", " acc" if accumulate else "", " shuf" if shuffle else ""),
+            " res" if r4 is not None else "", " acc" if accumulate else "", (" shuf" if shuffle else "") + (" wino" if wino else "")),
             2.0 * n * pc.cout * (pc.cin // pc.groups) * pc.kh * pc.kw * ho * wo))
     return out
 

@@ -382,7 +382,10 @@ def main():
                 "traffic_unit": None if traffic is None else
                 "HBM bytes per launch: rocprofv3 2 x FETCH_SIZE + WRITE_SIZE (%s); uncorrected %.4g" % (traffic["source"],
                                                                                                        traffic["raw"]),
-                "kernel": "conv family (fp32 MFMA implicit GEMM: conv_ws3 / conv_ws / conv_ws16 / conv_mfma)" if not split_mode
+                "executed": conv["tflops_executed"],
+                "executed_note": "TFLOP/s the matrix pipe was given: the 3x3 TFC layers of MDX-Net run the Winograd F(2,3)-along-rows "
+                                 "kernel (conv_ws3w), 2/3 of the algorithmic multiply-adds; `achieved` counts every layer's direct-form flops",
+                "kernel": "conv family (fp32 MFMA: conv_ws3 / conv_ws3m16h implicit GEMM, conv_ws3w Winograd F(2,3))" if not split_mode
                 else "conv family (split precision: conv_ws3s on the bf16 MFMA, 3 MFMAs per product -- achieved and peak are "
                      "in fp32-equivalent TFLOP/s, peak = 2516.6 / 3; the f0 models' layers run the fp32 kernels)",
                 "measured": "HIP events around every launch of one extra step of the same work, taken right behind the timed "
