@@ -92,6 +92,11 @@ __device__ __forceinline__ float buf_load_f32_s(const BufRsrc& r, unsigned voff,
     if ((unsigned long)voff + 4 > r.num_records) return 0.f;   // like the hardware: the scalar offset is not range checked
     return *reinterpret_cast<const float*>(r.base + voff + soff);
 }
+__device__ __forceinline__ float4 buf_load_f32x4_s(const BufRsrc& r, unsigned voff, unsigned soff) {   // dword-aligned
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((unsigned long)voff + 16 <= r.num_records) __builtin_memcpy(&v, r.base + voff + soff, 16);
+    return v;
+}
 #else
 // The raw-buffer intrinsics are bound by name (the clang builtin __builtin_amdgcn_raw_buffer_load_b128 of ROCm 7.2 lowers to
 // a 32-bit load and splats it); the resource is the classic 4-dword descriptor {base[47:0], stride 0, num_records, flags}.
@@ -114,6 +119,10 @@ __device__ __forceinline__ float buf_load_f32(const BufRsrc& r, unsigned voff) {
 // excluded), so the caller guarantees that base + voff + soff is inside the tensor whenever voff is in range.
 __device__ __forceinline__ float buf_load_f32_s(const BufRsrc& r, unsigned voff, unsigned soff) {
     return llvm_amdgcn_raw_buffer_load_f32(r.d, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ float4 buf_load_f32x4_s(const BufRsrc& r, unsigned voff, unsigned soff) {   // dword-aligned address
+    const buf_f32x4 v = llvm_amdgcn_raw_buffer_load_v4f32(r.d, (int)voff, (int)soff, 0);
+    return make_float4(v.x, v.y, v.z, v.w);
 }
 __device__ __forceinline__ float4 buf_load_f32x4(const BufRsrc& r, unsigned voff) {
     const buf_f32x4 v = llvm_amdgcn_raw_buffer_load_v4f32(r.d, (int)voff, 0, 0);

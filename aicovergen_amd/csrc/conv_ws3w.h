@@ -103,10 +103,12 @@ __global__ void __launch_bounds__(64 * ROWS + 256) conv_ws3w_kernel(ConvArgs p) 
         // patch items of this thread: (parity, input row, pair j), item ids pt + 256 e
         const float* xg = p.x;
         unsigned coff[NI][4];
+        bool wide = false;             // the tile's 66 input columns all exist: an item's four columns are ONE (dword-aligned) 16-byte load
         auto place = [&](int tile) {   // this thread's patch offsets inside tile `tile`
             const int tw_i = tile % p.tiles_w, th_i = (tile / p.tiles_w) % p.tiles_h, n = tile / (p.tiles_w * p.tiles_h);
             const int w0 = tw_i * (2 * kWinoPairs), h0 = th_i * ROWS;
             xg = p.x + (long)n * p.x_sn;
+            wide = w0 >= 1 && w0 + 2 * kWinoPairs < p.W && !(kAblate && (p.dbg & 512));
 #pragma unroll
             for (int e = 0; e < NI; ++e) {
                 const int item = pt + e * 256;
@@ -122,14 +124,14 @@ __global__ void __launch_bounds__(64 * ROWS + 256) conv_ws3w_kernel(ConvArgs p) 
             }
         };
         const unsigned ch2 = 8u * (unsigned)p.x_sc;          // byte distance of two channels: element e -> e + 1 of a quad
-        // Two stages of loads are in flight: under a full chip a round trip to L2 / HBM is about as long as a stage's MFMAs, so the
-        // loads of stage g + 2 are issued before stage g + 1 is committed (register sets A and B alternate; vmcnt is in order).
+        // One stage of loads is in flight (issued behind the commit of the previous one, a whole stage of MFMAs to land; a second set
+        // two stages ahead measured no different).  Where the loads are conditional -- three forms below -- the compiler's in-order vmcnt
+        // bookkeeping falls back to full waits, which is what a commit needs anyway.
         struct Staged { float4 wv[WR]; float d[NI][4][4]; };   // [item][channel e][column k]
-        Staged A, B;
+        Staged A;
         int lk = 0, lc = 0;                                  // load cursor: tile index of this workgroup, chunk
         auto load = [&](Staged& t) {
-            // past the last stage the loads are still issued, against empty buffers (no traffic, zeros): a conditional load would
-            // leave the compiler's in-order vmcnt bookkeeping with "0 outstanding" on one path and force full waits on the other
+            // past the last stage the loads are still issued, against empty buffers (no traffic, zeros)
             const bool live = lk < my_tiles;
             if (live && lc == 0) place(first + slot + lk * slots);
             const long wbase = (long)lc * 2 * p.Mpad * 4;    // floats: chunk c of every tap starts (c * 2 * Mpad) float4 in
@@ -138,17 +140,27 @@ __global__ void __launch_bounds__(64 * ROWS + 256) conv_ws3w_kernel(ConvArgs p) 
             for (int e = 0; e < WR; ++e) t.wv[e] = (kAblate && (p.dbg & 32)) ? make_float4(0.f, 0.f, 0.f, 0.f) : buf_load_f32x4(wb, woff[e]);
             const long left = (long)(p.Cin_g - lc * 8) * p.x_sc * 4;  // bytes up to the end of the channels: absent channels read 0
             const BufRsrc xb = make_buf(xg + (long)lc * 8 * p.x_sc, live ? (unsigned)lmin(left, 0x7fffffffL) : 0u);
-            if (lc * 8 + 8 <= p.Cin_g) {
-                // a whole chunk: the channel step rides in the scalar offset -- a producer VALU instruction takes issue slots from the
-                // consumer wave on its SIMD (measured: the address adds and the transform below cost 0.4 ms of MDX level 0's 3.8)
+            // A whole chunk: the channel step rides in the scalar offset (not range checked: fine, the channels exist) -- a producer
+            // VALU instruction takes issue slots from the consumer wave on its SIMD.  Interior tile: one 16-byte load per (item,
+            // channel) instead of four dword loads; returning loads, too, slow the consumer waves down (ablation).
+            if (lc * 8 + 8 <= p.Cin_g && wide && !(kAblate && (p.dbg & (4 | 128)))) {
+#pragma unroll
+                for (int it = 0; it < NI; ++it)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float4 q = buf_load_f32x4_s(xb, coff[it][0], (unsigned)e * ch2);
+                        t.d[it][e][0] = q.x; t.d[it][e][1] = q.y; t.d[it][e][2] = q.z; t.d[it][e][3] = q.w;
+                    }
+            } else if (lc * 8 + 8 <= p.Cin_g) {
 #pragma unroll
                 for (int it = 0; it < NI; ++it)
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
-                            t.d[it][e][k] = (kAblate && (p.dbg & 4)) ? 0.f : (kAblate && (p.dbg & 128)) ? (float)(coff[it][k] + (unsigned)e * ch2)
-                                                                                                         : buf_load_f32_s(xb, coff[it][k], (unsigned)e * ch2);
+                            if (kAblate && (p.dbg & 4)) t.d[it][e][k] = 0.f;
+                            else if (kAblate && (p.dbg & 128)) t.d[it][e][k] = __builtin_bit_cast(float, coff[it][k] & 0x3fffffu);   // no memory, the transform stays
+                            else t.d[it][e][k] = buf_load_f32_s(xb, coff[it][k], (unsigned)e * ch2);
             } else {
 #pragma unroll
                 for (int it = 0; it < NI; ++it)
@@ -172,6 +184,17 @@ __global__ void __launch_bounds__(64 * ROWS + 256) conv_ws3w_kernel(ConvArgs p) 
                 if (item >= 2 * PLANE) continue;
                 const int par = item / PLANE, rem = item - par * PLANE;
                 float v[4][4];                               // [point][channel e]
+#ifndef AICG_EMULATED
+                if (kAblate && (p.dbg & 256)) {              // the loads are waited for and dropped: no transform
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) asm volatile("" :: "v"(t.d[it][e][k]));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xs[(par * 4 + q) * PLANE + rem] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    continue;
+                }
+#endif
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     v[0][e] = t.d[it][e][0] - t.d[it][e][2];
@@ -186,26 +209,11 @@ __global__ void __launch_bounds__(64 * ROWS + 256) conv_ws3w_kernel(ConvArgs p) 
         };
         const int total = my_tiles * nchunk;
         if (total == 0) return;
-        if constexpr (M16) {   // one stage ahead: three patch items a thread leave no registers for a second set at three waves per SIMD
+        load(A);
+        for (int g = 0; g < total; ++g) {
+            commit(g, A);
             load(A);
-            for (int g = 0; g < total; ++g) {
-                commit(g, A);
-                load(A);
-                lds_barrier();  // stage g published (and the consumers are done with stage g - 1)
-            }
-        } else {
-            load(A);
-            load(B);
-            for (int g = 0;; g += 2) {
-                commit(g, A);
-                load(A);
-                lds_barrier();
-                if (g + 1 >= total) break;
-                commit(g + 1, B);
-                load(B);
-                lds_barrier();
-                if (g + 2 >= total) break;
-            }
+            lds_barrier();  // stage g published (and the consumers are done with stage g - 1)
         }
         return;
     }

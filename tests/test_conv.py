@@ -97,11 +97,12 @@ def test_conv2d(dev, ci, co, kh, kw, s, p, H, W):
 
 @pytest.mark.parametrize("n,ci,co,H,W,act", [(2, 8, 32, 4, 64, ops.ACT_RELU), (1, 20, 48, 7, 70, ops.ACT_RELU), (1, 16, 96, 5, 130, ops.ACT_NONE),
                                               (1, 40, 144, 9, 66, ops.ACT_RELU), (1, 24, 64, 3, 2, ops.ACT_NONE), (2, 12, 48, 11, 70, ops.ACT_RELU),
-                                              (1, 16, 40, 8, 64, ops.ACT_NONE), (1, 8, 240, 3, 36, ops.ACT_RELU)])
+                                              (1, 16, 40, 8, 64, ops.ACT_NONE), (1, 8, 240, 3, 36, ops.ACT_RELU), (1, 16, 48, 9, 200, ops.ACT_RELU),
+                                              (1, 12, 96, 5, 260, ops.ACT_NONE)])
 def test_conv2d_winograd_rows(dev, monkeypatch, n, ci, co, H, W, act):
     """F(2, 3) along rows (csrc/conv_ws3w.h) on TFC-shaped layers: every tile height (32 / 64 / 96 output channels on the 32 x 32 x 2
     MFMA, 48 -- also 144 = 3 x 48 and 240 = 5 x 48 -- on 16 x 16 x 4 with eight output rows a workgroup), ragged rows,
-    column tiles and channel chunks, output written into a channel slice.  Same products up to the exact 1/2 of G; the sums of the
+    column tiles (interior ones take 16-byte patch loads) and channel chunks, output written into a channel slice.  Same products up to the exact 1/2 of G; the sums of the
     transformed operands round differently from the direct form, hence 2e-6 rather than bit equality."""
     monkeypatch.setattr(ops, "winograd_min_positions", 1)
     torch.manual_seed(H * W + ci)

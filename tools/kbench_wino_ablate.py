@@ -10,7 +10,7 @@ w = torch.randn(c, c, 3, 3, device=dev) * 0.05
 pc = ops.PackedConv(w, torch.randn(c, device=dev), padding=1, device=dev)
 out = torch.empty_like(x)
 ops.winograd_min_positions = 1
-NAMES = [("full", 0), ("full + clock", 64), ("MFMA only + clock", 126), ("no x loads + clock", 68), ("x loads replaced by register moves (transform + commit stay)", 128), ("no MFMA / LDS reads", 1), ("MFMA on one LDS address", 2), ("no x loads", 4), ("no w loads", 32), ("no loads", 36),
+NAMES = [("full", 0), ("full + clock", 64), ("MFMA only + clock", 126), ("no x loads + clock", 68), ("x loads replaced by register moves (transform + commit stay)", 128), ("x loads issued, results unused (no transform)", 256), ("dword patch loads on interior tiles too", 512), ("no MFMA / LDS reads", 1), ("MFMA on one LDS address", 2), ("no x loads", 4), ("no w loads", 32), ("no loads", 36),
                    ("no commit", 8), ("no epilogue", 16), ("no loads, no commit", 44), ("MFMA only (no loads/commit/epilogue, one address)", 62),
                    ("producer only", 17)]
 if "AICG_CONV_ABLATE" not in os.environ:   # the switch is read once per process: one child per setting
