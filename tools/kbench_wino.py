@@ -1,7 +1,9 @@
 """MDX-Net TFC 3 x 3 layers (batch 16): Winograd F(2, 3)-along-rows kernel (conv_ws3w.h) against the direct implicit GEMM."""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
-from aicovergen_amd import ops  # noqa: E402
+from aicovergen_amd import _lib, ops  # noqa: E402
+if os.environ.get("AICG_LIB"):
+    _lib._use_library_for_tests(os.environ["AICG_LIB"], "hip")
 dev = torch.device("cuda:0")
 
 
