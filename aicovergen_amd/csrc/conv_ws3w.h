@@ -226,172 +226,172 @@ __global__ void __launch_bounds__(64 * ROWS + 256) conv_ws3w_kernel(ConvArgs p) 
     if (kAblate && (p.dbg & 64)) { clk0 = clock64(); wall0 = wall_clock64(); }
 #endif
     if constexpr (!M16) {
-    const int half = lane >> 5, l31 = lane & 31;
-    f32x16 acc[4][TM];
-    for (int k = 0; k < my_tiles; ++k) {
-    const int tile = first + slot + k * slots;
-    const int tw_i = tile % p.tiles_w, th_i = (tile / p.tiles_w) % p.tiles_h, n = tile / (p.tiles_w * p.tiles_h);
-    const int w0 = tw_i * (2 * kWinoPairs), h0 = th_i * ROWS;
+        const int half = lane >> 5, l31 = lane & 31;
+        f32x16 acc[4][TM];
+        for (int k = 0; k < my_tiles; ++k) {
+            const int tile = first + slot + k * slots;
+            const int tw_i = tile % p.tiles_w, th_i = (tile / p.tiles_w) % p.tiles_h, n = tile / (p.tiles_w * p.tiles_h);
+            const int w0 = tw_i * (2 * kWinoPairs), h0 = th_i * ROWS;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {   // accumulator rows r4 * 4 .. + 3 are output channels i * 32 + 8 r4 + 4 half .. + 3
-            const float4 bv = *reinterpret_cast<const float4*>(bias_s + i * 32 + 8 * r4 + 4 * per_tile_lane(half));
-            acc[1][i][r4 * 4 + 0] = bv.x; acc[1][i][r4 * 4 + 1] = bv.y; acc[1][i][r4 * 4 + 2] = bv.z; acc[1][i][r4 * 4 + 3] = bv.w;
+                for (int r4 = 0; r4 < 4; ++r4) {   // accumulator rows r4 * 4 .. + 3 are output channels i * 32 + 8 r4 + 4 half .. + 3
+                    const float4 bv = *reinterpret_cast<const float4*>(bias_s + i * 32 + 8 * r4 + 4 * per_tile_lane(half));
+                    acc[1][i][r4 * 4 + 0] = bv.x; acc[1][i][r4 * 4 + 1] = bv.y; acc[1][i][r4 * 4 + 2] = bv.z; acc[1][i][r4 * 4 + 3] = bv.w;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[0][i][r4 * 4 + r] = acc[2][i][r4 * 4 + r] = acc[3][i][r4 * 4 + r] = 0.f;
-        }
-    for (int c = 0; c < nchunk; ++c, ++g) {
-        lds_barrier();  // stage g is in LDS
-        if (kAblate && (p.dbg & 1)) continue;
-        // B fragments: plane (half, point q), input row wave + kh, pair l31;  A fragments: slab (tap, half), row i * 32 + l31
-        const float4* xq = xs0 + (g & 1) * XS4 + (half * 4) * PLANE + wave * kWinoPairs + l31;
-        const float4* wq = ws0 + (g & 1) * WS4 + half * BM + l31;
-        // One step = the four MFMAs (k = 4 channels of this lane half) of tap t = kh * 4 + q on row block i.  Steps run in units of U
-        // with different accumulators, their MFMAs interleaved, and a unit's fragments are read while the previous unit computes,
-        // in an order the scheduler may not change: left to itself it gathers the reads into bursts and the matrix pipe drains
-        // while a burst lands.  (What remains is the hand-over cost DESIGN 2.1 measured: ~74 cycles per MFMA instead of 64.)
-        constexpr int S = 12 * TM, U = TM >= 2 ? TM : 2;
-        float4 af[S], bf[12];
-        auto fetch = [&](int st) {
-            const int t = st / TM, i = st - t * TM;
-            const bool one = kAblate && (p.dbg & 2);
-            af[st] = wq[one ? 0 : t * 2 * BM + i * 32];
-            if (i == 0) bf[t] = xq[one ? 0 : (t & 3) * PLANE + (t >> 2) * kWinoPairs];
-        };
-#pragma unroll
-        for (int st = 0; st < U; ++st) fetch(st);
-#pragma unroll
-        for (int u0 = 0; u0 < S; u0 += U) {
-#pragma unroll
-            for (int st = u0 + U; st < u0 + 2 * U; ++st)
-                if (st < S) fetch(st);
-            sched_fence();
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int st = u0; st < u0 + U; ++st) {
-                    const int t = st / TM, i = st - t * TM, q = t & 3;
-                    const float av = e == 0 ? af[st].x : e == 1 ? af[st].y : e == 2 ? af[st].z : af[st].w;
-                    const float bv = e == 0 ? bf[t].x : e == 1 ? bf[t].y : e == 2 ? bf[t].z : bf[t].w;
-                    acc[q][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[q][i], 0, 0, 0);
+                    for (int r = 0; r < 4; ++r) acc[0][i][r4 * 4 + r] = acc[2][i][r4 * 4 + r] = acc[3][i][r4 * 4 + r] = 0.f;
                 }
-            sched_fence();
-        }
-    }
-    // ---- epilogue: Y(2 j) = M0 + M1 + M2, Y(2 j + 1) = M1 - M2 - M3 (bias inside M1), activation; lane j stores the pair as one float2
-    const int ho = h0 + wave, wo = w0 + 2 * l31;
-    if (tile >= ntiles || ho >= p.Ho || wo >= p.Wo || (kAblate && (p.dbg & 16))) continue;
-    const bool pair_ok = wo + 1 < p.Wo;
-    float* yrow = p.y + (long)n * p.y_sn + (long)ho * p.y_sh + wo;
-    const long y_sc = per_tile(p.y_sc);
-    const int row0 = per_tile_lane(m_base + 4 * half);
-    const bool al8 = ((p.y_sn | p.y_sc | p.y_sh) & 1) == 0 && ((uintptr_t)p.y & 7) == 0;
-    auto body = [&](auto act_tag) {
-        constexpr int ACT = decltype(act_tag)::value;
+            for (int c = 0; c < nchunk; ++c, ++g) {
+                lds_barrier();  // stage g is in LDS
+                if (kAblate && (p.dbg & 1)) continue;
+                // B fragments: plane (half, point q), input row wave + kh, pair l31;  A fragments: slab (tap, half), row i * 32 + l31
+                const float4* xq = xs0 + (g & 1) * XS4 + (half * 4) * PLANE + wave * kWinoPairs + l31;
+                const float4* wq = ws0 + (g & 1) * WS4 + half * BM + l31;
+                // One step = the four MFMAs (k = 4 channels of this lane half) of tap t = kh * 4 + q on row block i.  Steps run in units of U
+                // with different accumulators, their MFMAs interleaved, and a unit's fragments are read while the previous unit computes,
+                // in an order the scheduler may not change: left to itself it gathers the reads into bursts and the matrix pipe drains
+                // while a burst lands.  (What remains is the hand-over cost DESIGN 2.1 measured: ~74 cycles per MFMA instead of 64.)
+                constexpr int S = 12 * TM, U = TM >= 2 ? TM : 2;
+                float4 af[S], bf[12];
+                auto fetch = [&](int st) {
+                    const int t = st / TM, i = st - t * TM;
+                    const bool one = kAblate && (p.dbg & 2);
+                    af[st] = wq[one ? 0 : t * 2 * BM + i * 32];
+                    if (i == 0) bf[t] = xq[one ? 0 : (t & 3) * PLANE + (t >> 2) * kWinoPairs];
+                };
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+                for (int st = 0; st < U; ++st) fetch(st);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                if (m >= p.Cout_g) continue;
-                float y0 = (acc[0][i][r] + acc[1][i][r]) + acc[2][i][r];
-                float y1 = (acc[1][i][r] - acc[2][i][r]) - acc[3][i][r];
-                y0 = act_static<ACT>(y0, p.act, p.act_slope);
-                y1 = act_static<ACT>(y1, p.act, p.act_slope);
-                float* dst = yrow + (long)m * y_sc;
-                if (pair_ok && al8) *reinterpret_cast<float2*>(dst) = make_float2(y0, y1);
-                else { dst[0] = y0; if (pair_ok) dst[1] = y1; }
+                for (int u0 = 0; u0 < S; u0 += U) {
+#pragma unroll
+                    for (int st = u0 + U; st < u0 + 2 * U; ++st)
+                        if (st < S) fetch(st);
+                    sched_fence();
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int st = u0; st < u0 + U; ++st) {
+                            const int t = st / TM, i = st - t * TM, q = t & 3;
+                            const float av = e == 0 ? af[st].x : e == 1 ? af[st].y : e == 2 ? af[st].z : af[st].w;
+                            const float bv = e == 0 ? bf[t].x : e == 1 ? bf[t].y : e == 2 ? bf[t].z : bf[t].w;
+                            acc[q][i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[q][i], 0, 0, 0);
+                        }
+                    sched_fence();
+                }
             }
-    };
-    if (p.act == AICG_ACT_NONE) body(std::integral_constant<int, 0>{});
-    else if (p.act == AICG_ACT_RELU) body(std::integral_constant<int, 1>{});
-    else body(std::integral_constant<int, 3>{});
-    }
-    } else {
-    // ---- 48 rows on 16 x 16 x 4: lane = (k slot ks, index l15); row blocks rb = 0..2 (channel rb * 16 + l15 of A, channels
-    // rb * 16 + 4 ks + r of the accumulator), pair blocks cb = 0..1 (pair cb * 16 + l15)
-    const int ks = lane >> 4, l15 = lane & 15;
-    const int par = ks & 1, e2 = ks >> 1;            // this slot's channels of a chunk: 2 (2 e2 + s) + par for k-step s = 0, 1
-    f32x4v acc[4][3][2];
-    for (int k = 0; k < my_tiles; ++k) {
-    const int tile = first + slot + k * slots;
-    const int tw_i = tile % p.tiles_w, th_i = (tile / p.tiles_w) % p.tiles_h, n = tile / (p.tiles_w * p.tiles_h);
-    const int w0 = tw_i * (2 * kWinoPairs), h0 = th_i * ROWS;
+            // ---- epilogue: Y(2 j) = M0 + M1 + M2, Y(2 j + 1) = M1 - M2 - M3 (bias inside M1), activation; lane j stores the pair as one float2
+            const int ho = h0 + wave, wo = w0 + 2 * l31;
+            if (tile >= ntiles || ho >= p.Ho || wo >= p.Wo || (kAblate && (p.dbg & 16))) continue;
+            const bool pair_ok = wo + 1 < p.Wo;
+            float* yrow = p.y + (long)n * p.y_sn + (long)ho * p.y_sh + wo;
+            const long y_sc = per_tile(p.y_sc);
+            const int row0 = per_tile_lane(m_base + 4 * half);
+            const bool al8 = ((p.y_sn | p.y_sc | p.y_sh) & 1) == 0 && ((uintptr_t)p.y & 7) == 0;
+            auto body = [&](auto act_tag) {
+                constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-    for (int rb = 0; rb < 3; ++rb) {
-        const float4 bv = *reinterpret_cast<const float4*>(bias_s + rb * 16 + 4 * per_tile_lane(ks));
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            acc[1][rb][cb][0] = bv.x; acc[1][rb][cb][1] = bv.y; acc[1][rb][cb][2] = bv.z; acc[1][rb][cb][3] = bv.w;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[0][rb][cb][r] = acc[2][rb][cb][r] = acc[3][rb][cb][r] = 0.f;
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                        if (m >= p.Cout_g) continue;
+                        float y0 = (acc[0][i][r] + acc[1][i][r]) + acc[2][i][r];
+                        float y1 = (acc[1][i][r] - acc[2][i][r]) - acc[3][i][r];
+                        y0 = act_static<ACT>(y0, p.act, p.act_slope);
+                        y1 = act_static<ACT>(y1, p.act, p.act_slope);
+                        float* dst = yrow + (long)m * y_sc;
+                        if (pair_ok && al8) *reinterpret_cast<float2*>(dst) = make_float2(y0, y1);
+                        else { dst[0] = y0; if (pair_ok) dst[1] = y1; }
+                    }
+            };
+            if (p.act == AICG_ACT_NONE) body(std::integral_constant<int, 0>{});
+            else if (p.act == AICG_ACT_RELU) body(std::integral_constant<int, 1>{});
+            else body(std::integral_constant<int, 3>{});
         }
-    }
-    for (int c = 0; c < nchunk; ++c, ++g) {
-        lds_barrier();  // stage g is in LDS
-        if (kAblate && (p.dbg & 1)) continue;
-        // 8-byte fragments out of the quads: float2 index = 2 x float4 index + e2
-        const float2* xq = reinterpret_cast<const float2*>(xs0 + (g & 1) * XS4 + (par * 4) * PLANE + wave * kWinoPairs + l15) + e2;
-        const float2* wq = reinterpret_cast<const float2*>(ws0 + (g & 1) * WS4 + par * BM + l15) + e2;
-        float2 af[12][3], bf[12][2];
-        auto fetch = [&](int t) {
-            const bool one = kAblate && (p.dbg & 2);
+    } else {
+        // ---- 48 rows on 16 x 16 x 4: lane = (k slot ks, index l15); row blocks rb = 0..2 (channel rb * 16 + l15 of A, channels
+        // rb * 16 + 4 ks + r of the accumulator), pair blocks cb = 0..1 (pair cb * 16 + l15)
+        const int ks = lane >> 4, l15 = lane & 15;
+        const int par = ks & 1, e2 = ks >> 1;            // this slot's channels of a chunk: 2 (2 e2 + s) + par for k-step s = 0, 1
+        f32x4v acc[4][3][2];
+        for (int k = 0; k < my_tiles; ++k) {
+            const int tile = first + slot + k * slots;
+            const int tw_i = tile % p.tiles_w, th_i = (tile / p.tiles_w) % p.tiles_h, n = tile / (p.tiles_w * p.tiles_h);
+            const int w0 = tw_i * (2 * kWinoPairs), h0 = th_i * ROWS;
 #pragma unroll
-            for (int rb = 0; rb < 3; ++rb) af[t][rb] = wq[one ? 0 : 2 * (t * 2 * BM + rb * 16)];
+            for (int rb = 0; rb < 3; ++rb) {
+                const float4 bv = *reinterpret_cast<const float4*>(bias_s + rb * 16 + 4 * per_tile_lane(ks));
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) bf[t][cb] = xq[one ? 0 : 2 * ((t & 3) * PLANE + (t >> 2) * kWinoPairs + cb * 16)];
-        };
-        fetch(0);
+                for (int cb = 0; cb < 2; ++cb) {
+                    acc[1][rb][cb][0] = bv.x; acc[1][rb][cb][1] = bv.y; acc[1][rb][cb][2] = bv.z; acc[1][rb][cb][3] = bv.w;
 #pragma unroll
-        for (int t = 0; t < 12; ++t) {   // tap t = kh * 4 + q: 12 MFMAs on six accumulators, the next tap's five reads in flight
-            if (t + 1 < 12) fetch(t + 1);
-            sched_fence();
-            const int q = t & 3;
+                    for (int r = 0; r < 4; ++r) acc[0][rb][cb][r] = acc[2][rb][cb][r] = acc[3][rb][cb][r] = 0.f;
+                }
+            }
+            for (int c = 0; c < nchunk; ++c, ++g) {
+                lds_barrier();  // stage g is in LDS
+                if (kAblate && (p.dbg & 1)) continue;
+                // 8-byte fragments out of the quads: float2 index = 2 x float4 index + e2
+                const float2* xq = reinterpret_cast<const float2*>(xs0 + (g & 1) * XS4 + (par * 4) * PLANE + wave * kWinoPairs + l15) + e2;
+                const float2* wq = reinterpret_cast<const float2*>(ws0 + (g & 1) * WS4 + par * BM + l15) + e2;
+                float2 af[12][3], bf[12][2];
+                auto fetch = [&](int t) {
+                    const bool one = kAblate && (p.dbg & 2);
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+                    for (int rb = 0; rb < 3; ++rb) af[t][rb] = wq[one ? 0 : 2 * (t * 2 * BM + rb * 16)];
 #pragma unroll
-                for (int cb = 0; cb < 2; ++cb)
+                    for (int cb = 0; cb < 2; ++cb) bf[t][cb] = xq[one ? 0 : 2 * ((t & 3) * PLANE + (t >> 2) * kWinoPairs + cb * 16)];
+                };
+                fetch(0);
+#pragma unroll
+                for (int t = 0; t < 12; ++t) {   // tap t = kh * 4 + q: 12 MFMAs on six accumulators, the next tap's five reads in flight
+                    if (t + 1 < 12) fetch(t + 1);
+                    sched_fence();
+                    const int q = t & 3;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+#pragma unroll
+                        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                            for (int rb = 0; rb < 3; ++rb)
+                                acc[q][rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(s ? af[t][rb].y : af[t][rb].x, s ? bf[t][cb].y : bf[t][cb].x,
+                                                                                        acc[q][rb][cb], 0, 0, 0);
+                    sched_fence();
+                }
+            }
+            const int ho = h0 + wave;
+            if (tile >= ntiles || ho >= p.Ho || (kAblate && (p.dbg & 16))) continue;
+            float* yrow = p.y + (long)n * p.y_sn + (long)ho * p.y_sh;
+            const long y_sc = per_tile(p.y_sc);
+            const int row0 = per_tile_lane(m_base + 4 * ks);
+            const bool al8 = ((p.y_sn | p.y_sc | p.y_sh) & 1) == 0 && ((uintptr_t)p.y & 7) == 0;
+            auto body = [&](auto act_tag) {
+                constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    const int wo = w0 + 2 * (cb * 16 + l15);
+                    if (wo >= p.Wo) continue;
+                    const bool pair_ok = wo + 1 < p.Wo;
 #pragma unroll
                     for (int rb = 0; rb < 3; ++rb)
-                        acc[q][rb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(s ? af[t][rb].y : af[t][rb].x, s ? bf[t][cb].y : bf[t][cb].x,
-                                                                                acc[q][rb][cb], 0, 0, 0);
-            sched_fence();
-        }
-    }
-    const int ho = h0 + wave;
-    if (tile >= ntiles || ho >= p.Ho || (kAblate && (p.dbg & 16))) continue;
-    float* yrow = p.y + (long)n * p.y_sn + (long)ho * p.y_sh;
-    const long y_sc = per_tile(p.y_sc);
-    const int row0 = per_tile_lane(m_base + 4 * ks);
-    const bool al8 = ((p.y_sn | p.y_sc | p.y_sh) & 1) == 0 && ((uintptr_t)p.y & 7) == 0;
-    auto body = [&](auto act_tag) {
-        constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            const int wo = w0 + 2 * (cb * 16 + l15);
-            if (wo >= p.Wo) continue;
-            const bool pair_ok = wo + 1 < p.Wo;
-#pragma unroll
-            for (int rb = 0; rb < 3; ++rb)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = row0 + rb * 16 + r;
-                    if (m >= p.Cout_g) continue;
-                    float y0 = (acc[0][rb][cb][r] + acc[1][rb][cb][r]) + acc[2][rb][cb][r];
-                    float y1 = (acc[1][rb][cb][r] - acc[2][rb][cb][r]) - acc[3][rb][cb][r];
-                    y0 = act_static<ACT>(y0, p.act, p.act_slope);
-                    y1 = act_static<ACT>(y1, p.act, p.act_slope);
-                    float* dst = yrow + (long)m * y_sc + wo;
-                    if (pair_ok && al8) *reinterpret_cast<float2*>(dst) = make_float2(y0, y1);
-                    else { dst[0] = y0; if (pair_ok) dst[1] = y1; }
+                        for (int r = 0; r < 4; ++r) {
+                            const int m = row0 + rb * 16 + r;
+                            if (m >= p.Cout_g) continue;
+                            float y0 = (acc[0][rb][cb][r] + acc[1][rb][cb][r]) + acc[2][rb][cb][r];
+                            float y1 = (acc[1][rb][cb][r] - acc[2][rb][cb][r]) - acc[3][rb][cb][r];
+                            y0 = act_static<ACT>(y0, p.act, p.act_slope);
+                            y1 = act_static<ACT>(y1, p.act, p.act_slope);
+                            float* dst = yrow + (long)m * y_sc + wo;
+                            if (pair_ok && al8) *reinterpret_cast<float2*>(dst) = make_float2(y0, y1);
+                            else { dst[0] = y0; if (pair_ok) dst[1] = y1; }
+                        }
                 }
+            };
+            if (p.act == AICG_ACT_NONE) body(std::integral_constant<int, 0>{});
+            else if (p.act == AICG_ACT_RELU) body(std::integral_constant<int, 1>{});
+            else body(std::integral_constant<int, 3>{});
         }
-    };
-    if (p.act == AICG_ACT_NONE) body(std::integral_constant<int, 0>{});
-    else if (p.act == AICG_ACT_RELU) body(std::integral_constant<int, 1>{});
-    else body(std::integral_constant<int, 3>{});
-    }
     }
 #ifndef AICG_EMULATED
     if (kAblate && (p.dbg & 64) && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
