@@ -168,7 +168,28 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
         }
         if (wino_bm) bm = (int)wino_bm;
         hipStream_t wst = (hipStream_t)stream;
-        const int rc = bm == 96 ? run_ws3w_96(p, wst) : bm == 64 ? run_ws3w_64(p, wst) : bm == 48 ? run_ws3w_48(p, wst) : run_ws3w_32(p, wst);
+        auto run = [&](ConvArgs& a, int tile) {
+            return tile == 96 ? run_ws3w_96(a, wst) : tile == 64 ? run_ws3w_64(a, wst) : tile == 48 ? run_ws3w_48(a, wst) : run_ws3w_32(a, wst);
+        };
+        int rc;
+        AICG_SWITCH(wino_split, "AICG_WINO_SPLIT", 1);
+        const long tiles4 = (long)p.N * idiv_up(Ho, 4) * idiv_up(Wo, 64);
+        AICG_SWITCH(wino_split_tiles, "AICG_WINO_SPLIT_TILES", 1024);   // tests lower it
+        if (wino_split && !wino_bm && M > 48 && M % 96 == 48 && tiles4 >= wino_split_tiles) {
+            // 144 / 240 / ... rows on a map large enough to fill the chip twice over: 96-row tiles (107 executed TFLOP/s) for all but the
+            // last 48 rows, which take the 48-row kernel (95) -- MDX level 2: 2.04 -> 1.82 ms; on the small level 4 two launches lose.
+            // The second launch sees the same layer through shifted pointers: row m of it is row M - 48 + m of the images
+            ConvArgs a = p, b = p;
+            a.Cout_g = M - 48;
+            b.Cout_g = 48;
+            if (b.bias) b.bias += M - 48;
+            b.y += (long)(M - 48) * p.y_sc;
+            b.w3 += (long)(M - 48) * 4;   // [tap][chunk][parity][Mpad][4]: rows are the float4 index
+            rc = run(a, 96);
+            if (rc == 0) rc = run(b, 48);
+        } else {
+            rc = run(p, bm);
+        }
         if (rc == 1) return fail(AICG_E_SHAPE, "aicg_conv_forward: wino layer too large for the kernel's 32-bit offsets");
         return rc;
     }

@@ -218,6 +218,23 @@ def _run_child(code, env_extra, token):
     assert out.returncode == 0 and token in out.stdout, out.stdout + out.stderr
 
 
+def test_winograd_row_split_in_a_subprocess():
+    """144 / 240 output channels on a large map: aicg_conv_forward runs the 96-row Winograd tiles on all but the last 48 rows and the
+    48-row kernel on those, through shifted bias / output / weight-image pointers (AICG_WINO_SPLIT_TILES lowers the map-size gate)."""
+    code = r'''
+ops.winograd_min_positions = 1
+for (n, ci, co, h, w) in [(1, 16, 144, 6, 130), (2, 12, 240, 5, 66)]:
+    x, wt, b = torch.randn(n, ci, h, w), torch.randn(co, ci, 3, 3) * 0.1, torch.randn(co)
+    pc = ops.PackedConv(wt, b, padding=1)
+    buf = torch.full((n, co + 2, h, w), 3.0)
+    ops.conv(x, pc, act=ops.ACT_RELU, out=buf[:, 1:1 + co])
+    e = rel(buf[:, 1:1 + co], F.relu(F.conv2d(x, wt, b, padding=1)))
+    assert e < 2e-6 and (buf[:, 0] == 3).all() and (buf[:, -1] == 3).all(), (n, ci, co, h, w, e)
+print("winograd split ok")
+'''
+    _run_child(code, {"AICG_WINO_SPLIT_TILES": "1"}, "winograd split ok")
+
+
 def test_16x16x4_fragment_kernels_in_a_subprocess():
     """conv_ws3m16_kernel (16-byte fragments on v_mfma_f32_16x16x4_f32; opt-in through AICG_CONV_V3M16=1: 48- and 16-row layers with
     >= 65 536 positions, the MDX-Net / RMVPE level-0 shapes) incl. a channel tail (40 of 48 channels in the last K chunk) and a
