@@ -224,6 +224,8 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
             const long padded = (long)idiv_up(M, cands[i]) * cands[i];
             if (padded < best) { best = padded; BM = cands[i]; }
         }
+        AICG_SWITCH(force_bm, "AICG_CONV_FORCE_BM", 0);
+        if (force_bm) BM = (int)force_bm;
     }
     const long npos = (long)p.N * Ho * Wo;
     hipStream_t st = (hipStream_t)stream;

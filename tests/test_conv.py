@@ -122,6 +122,31 @@ def test_conv2d_winograd_rows(dev, monkeypatch, n, ci, co, H, W, act):
     assert rel_rms(y, ref + r) < 1e-5
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("c,h,w", [(48, 256, 3072), (96, 128, 1536), (144, 64, 768), (240, 16, 192)])
+def test_winograd_at_mdx_level_sizes(c, h, w):
+    """The Winograd form at the real MDX-Net level shapes (batch 2: every tile kind, the 96 + 48-row split of the 144-channel level,
+    interior 16-byte patch loads, the persistent walk over > 1 tile per workgroup) against the direct kernels -- themselves gated
+    against torch above -- with the per-layer bound the emulator test uses."""
+    import conftest
+    conftest._bind("hip")
+    torch.manual_seed(c)
+    x = torch.randn(2, c, h, w, device="cuda")
+    wt = torch.randn(c, c, 3, 3) * 0.05
+    pc = ops.PackedConv(wt, torch.randn(c) * 0.1, padding=1, device="cuda")
+    assert pc.w_wino is not None
+    old = ops.winograd_min_positions
+    try:
+        ops.winograd_min_positions = 1 << 60
+        ref = ops.conv(x, pc, act=ops.ACT_RELU)
+        ops.winograd_min_positions = 1
+        got = ops.conv(x, pc, act=ops.ACT_RELU)
+    finally:
+        ops.winograd_min_positions = old
+    assert not torch.equal(got, ref)          # a different summation order: the other kernel really ran
+    assert rel_rms(got, ref) < 2e-6
+
+
 def test_conv_strided_views(dev):
     """Outputs may be channel slices of a larger buffer (decoder concat without a copy, rmvpe.py:166)."""
     torch.manual_seed(11)
