@@ -52,6 +52,9 @@ def test_default_line_has_the_cpu_baseline():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["ref_cpu_seconds"] > 0 and c["ref_threads"] >= 1     # the reference's own C1 time rides along
     assert d["config"]["profiled_step_ms"] > 0 and len(d["config"]["per_rank_seconds_per_step"]) == 1
+    # `achieved` counts every layer's direct-form flops; `executed` is what the matrix pipe was given -- the Winograd layers 2/3
+    r = d["roofline"]
+    assert 0.6 * r["achieved"] < r["executed"] < r["achieved"] and "Winograd" in r["executed_note"]
 
 
 def test_stage_table_and_traffic_helpers():
