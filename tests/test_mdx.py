@@ -31,6 +31,26 @@ def test_unet_matches_oracle(dev):
     assert rel_rms(net(spec), ref) < 1e-4
 
 
+def test_unet_on_the_winograd_layers_matches_oracle(dev, monkeypatch):
+    """The same network with every eligible 3 x 3 TFC layer on the Winograd F(2, 3) kernel (csrc/conv_ws3w.h) -- at this size the
+    map-size gate would keep them on the direct kernels: the selection in ops.conv, the transformed weight image of PackedConv and
+    the bias / ReLU epilogue inside the whole forward, same tolerance."""
+    from aicovergen_amd import ops
+    monkeypatch.setattr(ops, "winograd_min_positions", 1)
+    cfg = weights.MDX_TINY
+    sd = weights.mdx_state_dict(cfg, 1234)
+    net = ConvTDFNet(sd, dev.device)
+    assert any(pc.w_wino is not None for blk in net.ds_dense + [net.mid] + net.us_dense for pc in blk.convs)
+    torch.manual_seed(0)
+    spec = torch.randn(2, 4, cfg["dim_f"], cfg["dim_t"])
+    with torch.no_grad():
+        ref = mdxnet.unet(sd, cfg, spec)
+    got = net(spec)
+    monkeypatch.setattr(ops, "winograd_min_positions", 1 << 60)
+    assert not torch.equal(got.cpu(), net(spec).cpu())      # the other kernels really ran
+    assert rel_rms(got, ref) < 1e-4
+
+
 def test_mdxmodel_stft_istft_layouts(dev):
     cfg = weights.MDX_TINY
     _, model, _ = _session(dev)
