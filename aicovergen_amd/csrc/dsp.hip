@@ -308,6 +308,10 @@ __global__ void __launch_bounds__(256) index_mix_kernel(float* __restrict__ feat
         else w[k] = w[k] / sum;
         if (id[k] < 0) id[k] = 0;   // weight 0: any valid row
     }
+    // No neighbour at all (every label -1: the probed inverted lists are empty, which k-means can produce at nprobe = 1): the
+    // reference divides 0 by 0 here and the frame becomes NaN.  Like the zero-distance rule above this keeps one degenerate frame from
+    // blanking a chunk: the frame keeps its own features.
+    if (!zeros && !(sum > 0.f)) return;
     for (int c = threadIdx.x; c < dim; c += 256) {
         const float f = feats[(long)r * dim + c];
         float acc = 0.f;

@@ -121,6 +121,8 @@ class HubertModel:
         assert source.dim() == 2 and source.shape[0] == 1, "one chunk at a time, as VC.vc calls it"
         return self.extract_features_many([source], output_layer)[0], padding_mask
 
+    max_tokens_per_pass = 32768   # extract_features_many: tokens laid side by side per transformer pass (~0.4 GB of fc1 output)
+
     def _frontend(self, source):
         """Waveform (1, N) -> (1, embed, T) in front of the encoder LayerNorm: feature-extractor convs, layer-0 GroupNorm + GELU,
         LayerNorm, projection, positional conv.  Everything here sees the chunk's boundaries (strided convs, whole-chunk GroupNorm
@@ -155,6 +157,22 @@ class HubertModel:
         `_frontend`) stays per chunk on column slices.  One chunk reproduces the single-chunk call exactly."""
         P, cfg = self._prepare(), self.cfg
         E, H = cfg["embed"], cfg["heads"]
+        # Token budget per pass: activation memory grows with the tokens laid side by side (fc1: ffn x tokens floats), so a very
+        # long track's chunks go through in groups (the GEMMs are far past chip-filling at this size).  Grouping only changes which
+        # chunks share a GEMM launch, i.e. tile selection and with it fp32 summation order: results differ by ~1e-6 relative between
+        # groupings, not bit for bit (see VC.pipeline's docstring).
+        if len(sources) > 1:
+            groups, cur, tok = [], [], 0
+            for src in sources:
+                t = (src.shape[-1] - 400) // 320 + 1
+                if cur and tok + t > self.max_tokens_per_pass:
+                    groups.append(cur)
+                    cur, tok = [], 0
+                cur.append(src)
+                tok += t
+            groups.append(cur)
+            if len(groups) > 1:
+                return [y for g in groups for y in self.extract_features_many(g, output_layer)]
         fronts = [self._frontend(src) for src in sources]
         lens = [f.shape[2] for f in fronts]
         offs = [0]

@@ -595,25 +595,37 @@ _gru_pending = []
 
 
 def gru_timed_out():
-    """True if any two-workgroup GRU launch since the last call reported a partner-exchange timeout (the partner workgroup
+    """True if any multi-workgroup GRU launch since the last call reported a partner-exchange timeout (the partner workgroup
     was not co-resident in time: a busy or shared GPU).  Call after the stream that ran them has been drained.  The result
     of such a launch is invalid; callers recompute with the single-workgroup kernel (`gru_bidir(two_workgroups=False)`)."""
-    flags, _gru_pending[:] = list(_gru_pending), []
+    pend, _gru_pending[:] = list(_gru_pending), []
     bad = False
-    for f in flags:
+    for f, _ in pend:
         bad = bad or int(f.item()) != 0
     return bad
 
 
 def gru_check_pending():
-    """Raise if a two-workgroup GRU launch timed out (for callers that cannot recompute)."""
+    """Raise if a multi-workgroup GRU launch timed out (for callers that cannot recompute)."""
     if gru_timed_out():
         raise RuntimeError("aicg_gru_bidir_2wg: partner workgroup exchange timed out")
 
 
+def _gru_repair_backlog():
+    """A caller that never polls gru_timed_out(): bound the backlog (this synchronises) and REPAIR instead of failing -- every pending
+    launch whose flag is set is recomputed by the single-workgroup kernel into the same output tensor, on the stream it is used on."""
+    pend, _gru_pending[:] = list(_gru_pending), []
+    for f, (gi, whh_t, bhh, out, hidden) in pend:
+        if int(f.item()) != 0:
+            _call("aicg_gru_bidir", _ptr(gi), _ptr(whh_t), _ptr(bhh), _ptr(out), hidden, gi.shape[1], _stream(gi))
+
+
 def gru_bidir(gi, whh_t, bhh, hidden, two_workgroups=None):
-    """gi: (6*hidden, T) channel-major input projections -> (2*hidden, T).  Default: the two-workgroup-per-direction
-    kernel (all of W_hh on chip); `two_workgroups=False` (or AICG_GRU_2WG=0) selects the single-workgroup kernel."""
+    """gi: (6*hidden, T) channel-major input projections -> (2*hidden, T).  Default: the multi-workgroup-per-direction
+    kernel (all of W_hh on chip); `two_workgroups=False` (or AICG_GRU_2WG=0) selects the single-workgroup kernel.
+    The multi-workgroup kernels need their workgroups co-resident; a launch that timed out waiting for a partner sets a flag that
+    pipeline() polls with gru_timed_out() (and recomputes).  Callers that never poll are covered too: once 16 launches are
+    pending, the flagged ones are recomputed in place by the single-workgroup kernel (_gru_repair_backlog)."""
     assert gi.is_contiguous() and gi.shape[0] == 6 * hidden
     t = gi.shape[1]
     out = torch.empty((2 * hidden, t), dtype=torch.float32, device=gi.device)
@@ -623,13 +635,11 @@ def gru_bidir(gi, whh_t, bhh, hidden, two_workgroups=None):
         # hidden 256 (every RMVPE): four workgroups per direction, all of W_hh in registers; other sizes: two (part of it in LDS)
         _call("aicg_gru_bidir_4wg" if hidden == 256 and GRU_WORKGROUPS == 4 else "aicg_gru_bidir_2wg", _ptr(gi), _ptr(whh_t), _ptr(bhh),
               _ptr(out), hidden, t, _ptr(scratch), _stream(gi))
-        # the kernel's exchange-timeout flag is read back lazily (gru_check_pending): an .item() here would park the host
+        # the kernel's exchange-timeout flag is read back lazily (gru_timed_out): an .item() here would park the host
         # until the recurrence ends, which is exactly the time pipeline() wants to spend queueing HuBERT work
-        _gru_pending.append(scratch[32 * hidden: 32 * hidden + 4].view(torch.int32))
+        _gru_pending.append((scratch[32 * hidden: 32 * hidden + 4].view(torch.int32), (gi, whh_t, bhh, out, hidden)))
         if len(_gru_pending) > 16:
-            # a caller that never checks: bound the backlog (this synchronises).  A timeout found here may belong to ANY of the
-            # pending launches, whose outputs were already handed out -- it cannot be repaired from here, so it is an error
-            gru_check_pending()
+            _gru_repair_backlog()
         return out
     _call("aicg_gru_bidir", _ptr(gi), _ptr(whh_t), _ptr(bhh), _ptr(out), hidden, t, _stream(gi))
     return out

@@ -193,8 +193,7 @@ class VC(object):
             replace_f0 = np.interp(list(range(delta_t)), inp_f0[:, 0] * 100, inp_f0[:, 1])
             shape = f0[self.x_pad * tf0: self.x_pad * tf0 + len(replace_f0)].shape[0]
             f0[self.x_pad * tf0: self.x_pad * tf0 + len(replace_f0)] = replace_f0[:shape]
-        dev = self.device if str(self.device) != "cpu" or ops._lib.backend() == "emu" else self.device
-        f0bak, coarse = ops.f0_coarse(torch.from_numpy(f0).to(dev), factor, f0_mel_min, f0_mel_max)
+        f0bak, coarse = ops.f0_coarse(torch.from_numpy(f0).to(self.device), factor, f0_mel_min, f0_mel_max)
         return coarse.cpu().numpy(), f0bak.cpu().numpy()
 
     # ---- one chunk ----------------------------------------------------------------------------------------------
@@ -353,7 +352,10 @@ class VC(object):
         """Same contract as the reference (:474-653): float32 16 kHz mono in, int16 at tgt_sr out.
         `noise_fn(chunk_index, start, end) -> (noise_z, noise_src)` injects the synthesizer noise (tests); `noise_seed`
         instead draws it from a per-chunk seeded device generator, which makes the output independent of how chunks are
-        distributed over ranks; `group` shards the chunk loop over the ranks of a torch.distributed process group."""
+        distributed over ranks UP TO fp32 SUMMATION ORDER: the HuBERT transformer runs once over all of a rank's chunks
+        (HubertModel.extract_features_many), so the GEMM tiles -- and the order of their fp32 sums -- depend on how many chunks a
+        rank owns; outputs of different world sizes agree to ~1e-6 relative (tests/test_dist.py states the bound), ranks of one run
+        agree bit for bit; `group` shards the chunk loop over the ranks of a torch.distributed process group."""
         if noise_fn is None and noise_seed is not None:
             inter, upp = net_g.inter_channels, net_g.upp
 

@@ -115,7 +115,7 @@ def make_rmvpe(name, cfg, seconds, seed):
     print(name, hidden.shape, float((f0 > 0).mean()))
 
 
-def make_pipeline(name, seconds, seed, full=False, x=(1, 1, 1, 2)):
+def make_pipeline(name, seconds, seed, full=False, x=(1, 1, 1, 2), f0_rows=None, resample_sr=0):
     """`full`: the full-size model set (HuBERT-base, RMVPE, 40 kHz v2 synthesizer) -- BASELINE config C1 when
     `seconds` = 30 and x = main.py's (3, 10, 60, 65) preset; the reference's f0 / coarse bins are stored too.
     End to end: the reference's own VC.pipeline (src/vc_infer_pipeline.py) + its synthesizer + its RMVPE, with
@@ -136,11 +136,22 @@ def make_pipeline(name, seconds, seed, full=False, x=(1, 1, 1, 2)):
     lib.feature = types.ModuleType("librosa.feature")
     lib.filters.mel = lambda sr, n_fft, n_mels, fmin, fmax, htk: orm.mel_filterbank(sr, n_fft, n_mels, fmin, fmax)
     lib.feature.rms = lambda y, frame_length, hop_length: opipe.rms_frames(y, frame_length, hop_length)
+    if resample_sr:
+        # librosa.resample (resampy's kaiser_best in librosa 0.9.1) is absent here: the branch at vc_infer_pipeline.py:641-644 runs
+        # with scipy's polyphase resampler in its place -- what the fixture pins is the branch's plumbing (change_rms BEFORE the
+        # resampling, peak normalisation and the int16 cast after it), not resampy's filter
+        from scipy.signal import resample_poly
+
+        def fake_resample(y, orig_sr, target_sr):
+            g = int(np.gcd(int(orig_sr), int(target_sr)))
+            return resample_poly(y, int(target_sr) // g, int(orig_sr) // g).astype(np.float32)
     lib.__spec__ = None
     sys.modules["librosa"], sys.modules["librosa.filters"], sys.modules["librosa.feature"] = lib, lib.filters, lib.feature
     sys.path.insert(0, REF)
     import rmvpe as ref_rmvpe
     import vc_infer_pipeline as ref_vc
+    if resample_sr:
+        ref_vc.librosa.resample = fake_resample   # (the module object the reference imported, whichever call stubbed it first)
     from infer_pack.models import SynthesizerTrnMs768NSFsid
     nets = weights.full_model_set(seed) if full else weights.small_model_set(seed)
     cfg = nets["synth_cfg"]
@@ -194,13 +205,29 @@ def make_pipeline(name, seconds, seed, full=False, x=(1, 1, 1, 2)):
     torch.randn_like = fake_randn_like
     import time
     t0 = time.time()
+    f0_file = None
+    if f0_rows is not None:
+        # the f0 curve file of the web UI (vc_infer_pipeline.py:511-519: "time [s], f0 [Hz]" per line; :349-358 splices it in)
+        import tempfile
+        tmp = tempfile.NamedTemporaryFile("w", suffix=".csv", delete=False)
+        tmp.write("\n".join("%.6f,%.6f" % (t, f) for t, f in f0_rows) + "\n")
+        tmp.close()
+        f0_file = types.SimpleNamespace(name=tmp.name)
     try:
-        out = vc.pipeline(Hub(), net_g, 0, audio, "x.wav", [0, 0, 0], 0, "rmvpe", "", 0.5, 1, 3, tgt_sr, 0, 0.25, "v2", 0.33, 128)
+        out = vc.pipeline(Hub(), net_g, 0, audio, "x.wav", [0, 0, 0], 0, "rmvpe", "", 0.5, 1, 3, tgt_sr, resample_sr, 0.25, "v2", 0.33,
+                          128, f0_file=f0_file)
     finally:
         torch.randn_like = orig
+        if f0_file is not None:
+            os.unlink(f0_file.name)
     extra = {}
+    if f0_rows is not None:
+        extra.update(f0_rows=np.asarray(f0_rows, dtype=np.float64), coarse=f0_seen["coarse"].astype(np.int16),
+                     f0=f0_seen["f0"].astype(np.float64))
+    if resample_sr:
+        extra.update(resample_sr=np.array([resample_sr]))
     if full:
-        extra = dict(coarse=f0_seen["coarse"].astype(np.int16), f0=f0_seen["f0"].astype(np.float64), x=np.array(x),
+        extra.update(coarse=f0_seen["coarse"].astype(np.int16), f0=f0_seen["f0"].astype(np.float64), x=np.array(x),
                      ref_cpu_seconds=np.array([time.time() - t0]), ref_threads=np.array([torch.get_num_threads()]))
     np.savez_compressed(os.path.join(HERE, name + ".npz"), seed=np.array([seed]), seconds=np.array([seconds]), audio=out, **extra)
     print(name, out.shape, out.dtype, int(np.abs(out).max()), "%.1f s" % (time.time() - t0))
@@ -212,6 +239,12 @@ if __name__ == "__main__":
         # BASELINE config C1: 30 s mono 16 kHz through the reference's own VC.pipeline on the CPU, full-size networks,
         # main.py's chunk preset (one 576 000-sample padded chunk)
         make_pipeline("pipeline_c1_30s", 30.0, 1234, full=True, x=(3, 10, 60, 65))
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "branches":
+        # the two public arguments rvc_infer never uses (src/rvc.py:150) but VC.pipeline accepts: an f0 curve file and resample_sr
+        rows = [(0.10 + 0.05 * i, 180.0 + 40.0 * np.sin(0.7 * i) + 3.0 * i) for i in range(24)]
+        make_pipeline("pipeline_small_f0file", 2.6, 1234, f0_rows=rows)
+        make_pipeline("pipeline_small_resample32k", 2.6, 1234, resample_sr=32000)
         sys.exit(0)
     make_synth("synth_tiny_T24", weights.SYNTH_CFG_TINY, 24, 1234)
     make_synth("synth_40k_T16", weights.SYNTH_CFG_40K_V2, 16, 1234)

@@ -106,6 +106,45 @@ def test_c1_pipeline_vs_reference_golden():
     assert np.array_equal(coarse[:n], g64["coarse"][:n])
 
 
+def test_c1_pipeline_with_the_references_f0_injected():
+    """BASELINE C1 with the chaotic part held fixed.  The free-running test above has to allow 1e-3: RMVPE's
+    f0 agrees with the reference's to 2.5e-7, but the vocoder's harmonic source integrates f0 over the whole 36 s chunk, so
+    equally accurate f0 roundings give waveforms 1.2e-4 ... 4.7e-4 apart.  Here the REFERENCE's own f0 track
+    (gold["f0"], what its get_f0 returned) replaces the estimator's output; everything else -- filtfilt, HuBERT, feature
+    plumbing, coarse bins, text encoder, flow, SineGen, vocoder, RMS mix, int16 -- is this implementation.  A regression in any
+    of those can no longer hide under the f0 -> phase sensitivity: the waveform must sit at accumulation-order distance from
+    the reference's."""
+    from test_pipeline import build, noise_fn_for
+    gold = np.load(os.path.join(GOLD, "pipeline_c1_30s.npz"))
+    seed, x = int(gold["seed"][0]), tuple(int(v) for v in gold["x"])
+    nets = weights.full_model_set(seed)
+    audio = vocal_like(float(gold["seconds"][0]), 16000, seed + 5)
+    import conftest
+    dev = conftest.Dev("hip")
+    vc, hub, net_g, tgt_sr = build(dev, nets, x)
+    orig = vc.get_f0
+    seen = {}
+
+    def with_reference_f0(*a, **k):
+        k["_raw_f0"] = gold["f0"].copy()
+        seen["coarse"], seen["f0"] = orig(*a, **k)
+        return seen["coarse"], seen["f0"]
+    vc.get_f0 = with_reference_f0
+    out = vc.pipeline(hub, net_g, 0, audio, "x.wav", [0, 0, 0], 0, "rmvpe", "", 0.5, 1, 3, tgt_sr, 0, 0.25, "v2", 0.33, 128,
+                      noise_fn=noise_fn_for(nets))
+    ref = gold["audio"]
+    n = min(len(seen["coarse"]), len(gold["coarse"]))
+    assert np.array_equal(seen["coarse"][:n], gold["coarse"][:n])      # same f0 in -> the quantiser must give the same bins: bit-exact
+    diff = np.abs(out.astype(np.int32) - ref.astype(np.int32))
+    rel = np.sqrt(np.sum(diff.astype(np.float64) ** 2) / np.sum(ref.astype(np.float64) ** 2))
+    print("C1, reference f0 injected: rel rms %.3e, max |diff| %d of peak %d, <= 1 LSB on %.5f, exact on %.4f"
+          % (rel, diff.max(), np.abs(ref).max(), (diff <= 1).mean(), (diff == 0).mean()))
+    # SURVEY 8(d)'s end-to-end bar, reachable once the f0 -> phase path is held fixed
+    assert rel <= 2e-5
+    assert (diff <= 1).mean() >= 0.999
+    assert diff.max() <= 3
+
+
 @pytest.mark.parametrize("n", [1056160, 640160])
 def test_chunk_hubert_and_synth_vs_oracle(n):
     """The chunk sizes of the two presets: (3,10,60,65) -> 1 056 160 samples, T_h = 3300 (4-way split attention, 64x64
@@ -143,7 +182,7 @@ def test_chunk_hubert_and_synth_vs_oracle(n):
 
 
 def test_240s_rmvpe_vs_oracle():
-    """Whole-track f0 of a 4-minute input: 24 001 frames padded to 24 032, the two-workgroup GRU over every step."""
+    """Whole-track f0 of a 4-minute input: 24 001 frames padded to 24 032, the (default) four-workgroup GRU over every step."""
     from aicovergen_amd.rmvpe import RMVPE
     from aicovergen_amd import ops
     sd = weights.rmvpe_state_dict(weights.RMVPE_FULL, 1235)

@@ -99,6 +99,50 @@ def test_crepe_full_matches_oracle():
     assert (bins.cpu().numpy() == ob).mean() > 0.98
 
 
+@pytest.mark.gpu
+def test_crepe_full_2048_frame_batch_vs_oracle():
+    """BASELINE C4 at the benched batch shape: 2 348 frames at hop 128 = ONE full 2048-frame network batch
+    (the _ToeplitzGemm with K up to 65 536 and the _RowConv over a 2048 x W plane at their real sizes) + a ragged 300-frame one,
+    decoded as 10 Viterbi sequences of 2 * hop = 256 frames (reference src/vc_infer_pipeline.py:116-126: batch_size = hop * 2).
+    Posteriors <= 1e-4; the Viterbi path is BIT-EQUAL to the oracle's decoder run on the HIP posteriors; every frame whose bin
+    differs from the all-oracle run is listed with its posterior margin (<= 0.2 % of the frames)."""
+    import conftest
+    conftest._bind("hip")
+    torch.set_num_threads(min(__import__("os").cpu_count() or 1, 32))
+    sd = weights.crepe_state_dict(weights.CREPE_FULL, 1234)
+    net = crepe.Crepe(sd, "cuda:0")
+    hop, n_frames = 128, 2048 + 300
+    audio = vocal_like((n_frames - 1) * hop / 16000.0 + 0.004, 16000, 9)[:(n_frames - 1) * hop + 37]
+    x = (audio / np.quantile(np.abs(audio), 0.999)).astype(np.float32)
+    assert 1 + len(x) // hop == n_frames
+    d = _dither(n_frames)
+    pitch, bins, post = crepe.predict(net, x, hop, batch_size=2 * hop, dither=d)          # frame_batch = 2048 (the default)
+    op, ob, opost = ocr.predict(sd, x, hop, batch_size=2 * hop, dither=d)
+    post_h = post.cpu().numpy()
+    e = rel_rms(post, torch.from_numpy(opost))
+    print("CREPE-full, %d frames: posteriors rel rms %.3e, max |diff| %.3e" % (n_frames, e, np.abs(post_h - opost).max()))
+    assert post_h.shape == (n_frames, 360) and e < 1e-4
+    # the decoder alone: oracle Viterbi on the HIP posteriors, sequence by sequence
+    lo, hi = ocr.frequency_to_bins(50.0), ocr.frequency_to_bins(1100.0, ceil=True)
+    want = []
+    for s0 in range(0, n_frames, 2 * hop):
+        logits = torch.from_numpy(post_h[s0:s0 + 2 * hop]).t().clone()
+        logits[:lo] = -float("inf")
+        logits[hi:] = -float("inf")
+        want.append(ocr.viterbi_path(torch.softmax(logits, 0).numpy()))
+    assert len(want) == 10
+    got = bins.cpu().numpy()
+    assert np.array_equal(got, np.concatenate(want)), "Viterbi path differs from the oracle decoder on identical posteriors"
+    # end to end against the all-oracle run: a disagreement needs a near-tie of the posterior (or rides on one through the path)
+    bad = np.nonzero(got != ob)[0]
+    for t in bad:
+        p2 = np.sort(opost[t, lo:hi])[-2:]
+        print("  frame %d: bin %d vs oracle %d, oracle posterior top1-top2 %.3e (top1 %.3e)" % (t, got[t], ob[t], p2[1] - p2[0], p2[1]))
+    print("CREPE-full bins: %d of %d frames differ from the all-oracle run" % (len(bad), n_frames))
+    assert len(bad) <= 0.002 * n_frames
+    assert np.allclose(pitch.cpu().numpy()[got == ob], op[got == ob], rtol=1e-5)
+
+
 def test_crepe_post_processing_matches_reference_golden(dev, monkeypatch):
     """SURVEY 8a row a13, pinned against the REFERENCE's own code: tests/golden/crepe_post_ref.npz holds the outputs of
     /root/reference/src/vc_infer_pipeline.py's get_f0_crepe_computation / get_f0_official_crepe_computation /

@@ -81,6 +81,55 @@ def test_pipeline_small_vs_reference_golden(dev):
     assert_bins_agree(coarse[:p_len], f0[:p_len], info["coarse"][:p_len], info["f0"][:p_len], info["hidden"])
 
 
+def test_f0_file_branch_vs_reference_golden(dev, tmp_path):
+    """The f0 curve file argument (reference src/vc_infer_pipeline.py:511-519 reads it, :349-358 splices it over the estimate from
+    x_pad seconds on): tests/golden/pipeline_small_f0file.npz is the REFERENCE's own VC.pipeline run with such a file
+    (make_golden.py branches).  rvc_infer never passes one (src/rvc.py:150), the web UI's upstream does."""
+    import types
+    gold = np.load(os.path.join(GOLD, "pipeline_small_f0file.npz"))
+    nets = weights.small_model_set(int(gold["seed"][0]))
+    audio = vocal_like(float(gold["seconds"][0]), 16000, int(gold["seed"][0]) + 5)
+    f = tmp_path / "curve.csv"
+    f.write_text("\n".join("%.6f,%.6f" % (t, v) for t, v in gold["f0_rows"]) + "\n")
+    vc, hub, net_g, tgt_sr = build(dev, nets)
+    seen = {}
+    orig = vc.get_f0
+
+    def spy(*a, **k):
+        seen["coarse"], seen["f0"] = orig(*a, **k)
+        return seen["coarse"], seen["f0"]
+    vc.get_f0 = spy
+    out = vc.pipeline(hub, net_g, 0, audio, "x.wav", [0, 0, 0], 0, "rmvpe", "", 0.5, 1, 3, tgt_sr, 0, 0.25, "v2", 0.33, 128,
+                      f0_file=types.SimpleNamespace(name=str(f)), noise_fn=noise_fn_for(nets))
+    # the spliced span is the file's curve exactly (np.interp on the same float32 rows), the rest the estimator's track
+    tf0 = vc.sr // vc.window
+    n_rep = int(np.round((gold["f0_rows"][:, 0].max() - gold["f0_rows"][:, 0].min()) * tf0 + 1))
+    lo = vc.x_pad * tf0
+    n = min(len(seen["f0"]), len(gold["f0"]))
+    assert np.allclose(seen["f0"][lo:lo + n_rep], gold["f0"][lo:lo + n_rep], rtol=1e-6, atol=1e-6)
+    assert not np.allclose(seen["f0"][lo:lo + n_rep], 0)                 # the curve really landed there
+    assert np.array_equal(seen["coarse"][lo:lo + n_rep], gold["coarse"][lo:lo + n_rep])
+    assert (np.asarray(seen["coarse"][:n]) != gold["coarse"][:n]).mean() <= 0.002
+    diff = np.abs(out.astype(np.int32) - gold["audio"].astype(np.int32))
+    assert out.shape == gold["audio"].shape and diff.max() <= 3 and (diff <= 1).mean() >= 0.999
+
+
+def test_resample_sr_branch_vs_reference_golden(dev):
+    """resample_sr != 0 (reference src/vc_infer_pipeline.py:639-644: change_rms at tgt_sr FIRST, then librosa.resample, then the
+    peak normalisation and the int16 cast).  The golden is the reference's own run with librosa.resample served by scipy's
+    polyphase resampler (librosa / resampy are not installable here; stated in make_golden.py): it pins the branch's order of
+    operations and output length, not resampy's filter."""
+    gold = np.load(os.path.join(GOLD, "pipeline_small_resample32k.npz"))
+    nets = weights.small_model_set(int(gold["seed"][0]))
+    audio = vocal_like(float(gold["seconds"][0]), 16000, int(gold["seed"][0]) + 5)
+    vc, hub, net_g, tgt_sr = build(dev, nets)
+    out = vc.pipeline(hub, net_g, 0, audio, "x.wav", [0, 0, 0], 0, "rmvpe", "", 0.5, 1, 3, tgt_sr, int(gold["resample_sr"][0]), 0.25,
+                      "v2", 0.33, 128, noise_fn=noise_fn_for(nets))
+    assert out.dtype == np.int16 and out.shape == gold["audio"].shape
+    diff = np.abs(out.astype(np.int32) - gold["audio"].astype(np.int32))
+    assert diff.max() <= 3 and (diff <= 1).mean() >= 0.999
+
+
 def assert_bins_agree(coarse, f0, want_coarse, want_f0, want_salience, max_rate=0.002):
     """The C1 test's criterion: coarse-pitch bins equal to the oracle's on >= 99.8 % of the frames; every other frame
     is listed with its f0 distance and the oracle's top-1 - top-2 salience margin and must be a neighbouring bin (a cents value
