@@ -2,6 +2,7 @@
 // the pointwise streaming kernel for 1x1 layers with <= 8 channels on one side.
 #include "conv_ws3s.h"
 #include "conv_ws3w.h"
+#include "conv_w2d.h"
 
 namespace aicg {
 
@@ -146,11 +147,24 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
     p.wsplit = d->packed_v3 && d->split ? w_packed + 2L * p.groups * p.w_group_stride : nullptr;
 
     if (d->wino) {
-        // Winograd F(2, 3) along rows (conv_ws3w.h): w_packed is the image pair of the (Cout, Cin, 3, 4) kernel, 12 taps
+        // Winograd F(2, 3) along rows (conv_ws3w.h): w_packed is the image pair of the (Cout, Cin, 3, 4) kernel, 12 taps;
+        // wino == 2: F(2 x 2, 3 x 3) (conv_w2d.h): w_packed is the [Cout / 48][Cin / 8][2][16][4][48] image of U = G g G^T
         if (p.KH != 3 || p.KW != 3 || p.sh != 1 || p.sw != 1 || p.dh != 1 || p.dw != 1 || p.ph != 1 || p.pw != 1 || pad_h_end != 1 ||
             pad_w_end != 1 || p.groups != 1 || res || p.accumulate || p.shuffle || p.res_mul || p.pre_act != AICG_ACT_NONE ||
-            p.out_scale != 1.f || !d->packed_v3 || (p.act != AICG_ACT_NONE && p.act != AICG_ACT_RELU) || Ho != p.H || Wo != p.W)
+            p.out_scale != 1.f || (!d->packed_v3 && d->wino < 2) || (p.act != AICG_ACT_NONE && p.act != AICG_ACT_RELU) || Ho != p.H || Wo != p.W)
             return fail(AICG_E_ARG, "aicg_conv_forward: wino needs a plain 3x3 / stride 1 / padding 1 layer (bias + none|ReLU epilogue)");
+        if (d->wino >= 2) {
+            AICG_SWITCH(w2d_ablate, "AICG_CONV_ABLATE", 0);
+            p.dbg = w2d_ablate;
+            p.w3 = w_packed;
+            // 2: eight waves (two per SIMD) on an 8 x 64 tile; 3: four waves (one per SIMD) on a 4 x 64 tile; 4 / 5: the same with the
+            // quad-fragment image ([s][p / 4][ks][m][p % 4]: one 16-byte fragment read per four MFMAs)
+            hipStream_t st2 = (hipStream_t)stream;
+            const int rc = d->wino == 2 ? run_w2d_8(p, st2) : d->wino == 3 ? run_w2d_4(p, st2) : d->wino == 4 ? run_w2d_8q(p, st2) : run_w2d_4q(p, st2);
+            if (rc == 1)
+                return fail(AICG_E_ARG, "aicg_conv_forward: wino 2 needs Cout %% 48 == 0, W %% 4 == 0, 16-byte aligned x with strides %% 4 == 0");
+            return rc;
+        }
         AICG_SWITCH(wino_ablate, "AICG_CONV_ABLATE", 0);
         p.dbg = wino_ablate;
         p.taps = 12;

@@ -1,0 +1,436 @@
+// 3 x 3 convolution (stride 1, dilation 1, padding 1) by the TWO-dimensional Winograd minimal-filtering form F(2 x 2, 3 x 3):
+// a 2 x 2 block of outputs from a 4 x 4 block of inputs with 16 multiplications per (input channel, output channel) where the
+// direct implicit GEMM spends 36 and the row-only form of conv_ws3w.h 24.
+//
+//     Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A                d: input rows 2 t - 1 .. 2 t + 2, columns 2 j - 1 .. 2 j + 2
+//     B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]    G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]    A^T = [1 1 1 0; 0 1 -1 -1]
+//
+// (the one-dimensional matrices of conv_ws3w.h applied along both axes; every constant is a power of two, so the result differs
+// from the direct form only by fp32 summation order).  The layer becomes SIXTEEN independent GEMMs (one per Winograd point
+// p = 4 i + q) of K = Cin over a quarter as many columns.  U = G g G^T is folded into the packed weights at load time
+// (ops.winograd2d_image); V = B^T d B is formed by the wave that consumes it, from the RAW input patch in LDS, in the issue slots
+// the matrix pipe leaves free (64 VALU additions per MFMA k-step of 96 MFMAs): no producer waves, no transformed planes in LDS --
+// the ablation of the row-only kernel priced its producers' VALU issue and returning loads at 0.7 of 3.67 ms.
+//
+// Geometry.  hipcc keeps MFMA accumulators in the 256 AGPRs of a wave, so a wave owns 16 points x 48 output channels (three 16-row
+// blocks: 48 is the channel granularity of every MDX-Net level) x 16 Winograd tiles = 192 accumulator registers of
+// v_mfma_f32_16x16x4_f32.  A workgroup of NW waves owns one M unit of 48 output channels x (NW output rows x 64 output columns) of one
+// image; wave w owns row pair w >> 1 and tile block w & 1 (column pairs 16 (w & 1) .. + 15).  NW = 8 (two waves per SIMD: one
+// wave's issue bubbles are the other's MFMA time; 192 AGPRs + 64 VGPRs each) or 4 (one per SIMD, any number of VGPRs, half the tile).
+// K runs in chunks of 8 input channels = 2 MFMA k-steps (lane group ks = lane >> 4 contracts channel 4 s + ks in step s).
+// One LDS stage per chunk, THREE buffers, filled by LDS DMA (buffer_load_dwordx4 ... lds: 1 KiB per wave-instruction, no staging
+// registers, zero padding by the buffer range check) that the same waves issue two stages ahead:
+//     weights  [s][p][ks][m = 0..47]  floats: 24 KiB, a contiguous slab of the packed image
+//     patch    [channel c = 0..7][row 0..NW+1][18 quads] (+ pad quads: the plane stride is 8 mod 16 quads, which puts the four ks groups
+//              of an 8-byte read on disjoint banks): input rows h0 - 1 .. h0 + NW, columns w0 - 4 .. w0 + 67, 16-byte aligned in HBM.
+// The k-steps form one software pipeline across chunk, tile and item boundaries: while the 48 MFMAs of k-step u run (16 points x 3
+// row blocks, one A fragment each), the wave reads the 4 x 4 raw patch of k-step u + 1 (a lane = tile column l15, channel ks; three
+// aligned 8-byte reads per patch row), forms its 16 V values a few additions per point, and prefetches the next point's fragments.
+// Stage g + 1 is complete in LDS when stage g starts (its DMA was waited for before the barrier), which is what lets k-step (g, 1)
+// read ahead into it; the DMA of stage g + 2 goes into the third buffer.
+// Epilogue: A^T M A in registers -- the 16 accumulators of an output never meet another lane --, bias, activation, float2 stores (the
+// first k-step of an item starts its accumulators from the inline constant 0 instead of adding to zeroed registers).
+// Persistent walk over (tile, M unit) items, M unit fastest, XCD x owning a contiguous eighth of the list: the workgroups that
+// share an input patch run side by side on one L2.
+#pragma once
+#include "conv_kernels.h"
+
+namespace aicg {
+
+typedef float w2d_f32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int kW2dM = 48;                                  // output channels per M unit
+static constexpr int kW2dCols = 64;                               // output columns of a workgroup's tile (its rows: NW)
+static constexpr int kW2dPQuads = (kW2dCols + 8) / 4;             // 18: patch columns w0 - 4 .. w0 + 67
+static constexpr int kW2dWFloats = 2 * 16 * 4 * kW2dM;            // 6144 floats of weights per chunk
+static constexpr int kW2dWPieces = kW2dWFloats / 256;             // 24 DMA pieces (1 KiB) of weights per chunk
+static constexpr int kW2dBufs = 3;
+// quads per channel plane of the patch: (NW + 2) rows of 18, rounded up to 8 mod 16
+__host__ __device__ constexpr int w2d_plane_quads(int nw) { return ((nw + 2) * kW2dPQuads + 7) / 16 * 16 + 8; }
+__host__ __device__ constexpr int w2d_stage_floats(int nw) { return kW2dWFloats + 8 * w2d_plane_quads(nw) * 4; }
+
+// One LDS-DMA piece: lane l fetches 16 bytes at buffer offset voff (+ the wave-uniform soff) and the hardware writes them to
+// lds_wave_base + 16 l.  Offsets >= the resource's num_records (kBufOob) deposit zeros -- the convolution's padding.
+__device__ __forceinline__ void w2d_dma16(const BufRsrc& r, unsigned voff, unsigned soff, float* lds_wave_base, int lane) {
+#ifdef AICG_EMULATED
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((unsigned long)voff + 16 <= r.num_records) __builtin_memcpy(&v, r.base + voff + soff, 16);
+    *reinterpret_cast<float4*>(lds_wave_base + 4 * lane) = v;
+#else
+    (void)lane;
+    // inline asm on purpose (tdf_pair.hip): with the builtin hipcc guards every following ds_read with a vmcnt(0); the stage-end
+    // w2d_dma_wait() orders it by hand.  M0 = LDS base of the piece, restored.
+    const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+    const unsigned so = __builtin_amdgcn_readfirstlane(soff);
+    buf_i32x4 rs;   // wave-uniform by construction; say so (a resource the compiler cannot prove uniform lands in VGPRs)
+    rs.x = __builtin_amdgcn_readfirstlane(r.d.x); rs.y = __builtin_amdgcn_readfirstlane(r.d.y);
+    rs.z = __builtin_amdgcn_readfirstlane(r.d.z); rs.w = __builtin_amdgcn_readfirstlane(r.d.w);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rs), "s"(lds), "s"(so)
+                 : "memory");
+#endif
+}
+__device__ __forceinline__ void w2d_dma_wait() {
+#ifndef AICG_EMULATED
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
+__device__ __forceinline__ void w2d_fence() {
+#ifndef AICG_EMULATED
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+template <class T>
+__device__ inline T w2d_opaque(T v) {   // a per-item copy of a uniform value the optimiser cannot hoist out of the walk
+#ifndef AICG_EMULATED
+    asm volatile("" : "+s"(v));
+#endif
+    return v;
+}
+
+// PF: points a fragment is fetched ahead (dword fragments: weights [s][p][ks][m]); PF == 0: QUAD fragments -- weights
+// [s][p / 4][ks][m][p % 4], one ds_read_b128 per (point group, row block) feeding four MFMAs, reloaded in place behind them.
+template <int NW, int PF>
+__global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
+    static_assert(PF == 0 || PF == 1 || PF == 3, "the fragment ring has PF + 1 slots and 16 points are a whole number of turns");
+    constexpr bool AQ = PF == 0;
+    constexpr int NT = 64 * NW;
+    constexpr int PROWS = NW + 2;                                 // patch rows
+    constexpr int PLANEQ = w2d_plane_quads(NW);
+    constexpr int STAGE = w2d_stage_floats(NW);
+    constexpr int PPIECES = 8 * PLANEQ / 64;                      // DMA pieces of patch per chunk (23 / 15)
+    static_assert(8 * PLANEQ % 64 == 0 && kW2dWPieces % NW == 0, "pieces are whole");
+    HIP_DYNAMIC_SHARED(float4, smem4)
+    float* const smem = reinterpret_cast<float*>(smem4);
+    float* const bias_s = smem + kW2dBufs * STAGE;   // Cout: the layer's bias
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, ks = lane >> 4;
+    const int nmu = p.Mpad;                          // M units (launch_conv_w2d stores Cout / 48 here)
+    const int nchunk = p.nchunk;
+    // persistent walk: item = tile * nmu + mu; XCD x owns a contiguous eighth of the item list, its workgroups take it `slots` at a time
+    const int ntiles = p.N * p.tiles_h * p.tiles_w;
+    const int nitems = ntiles * nmu;
+    const int slots = gridDim.x >> 3, per_xcd = (nitems + 7) >> 3;
+    const int first = (blockIdx.x & 7) * per_xcd, slot = blockIdx.x >> 3;
+    const int mine = nitems - first < per_xcd ? nitems - first : per_xcd;
+    const int my_items = slot < mine ? (mine - slot + slots - 1) / slots : 0;
+    if (my_items <= 0) return;
+
+    for (int i = tid; i < nmu * kW2dM; i += NT) bias_s[i] = p.bias ? p.bias[i] : 0.f;
+
+    // ---- DMA plan of this wave: weight pieces w WPW .. + WPW - 1, patch pieces w, w + NW, ...  Only the byte offsets of the patch quads
+    // stay in registers: what a lane fetches of a piece is decoded again per item (a hundred VALU operations against ~40 000 MFMA cycles)
+    constexpr int WPW = kW2dWPieces / NW;            // weight pieces per wave (3 / 6)
+    constexpr int NPP = (PPIECES + NW - 1) / NW;     // patch pieces per wave (3 / 4)
+    unsigned poff[NPP];
+    const float* xg = p.x;
+    int li = 0, lc = 0, lmu = 0;                     // DMA cursor: item of this workgroup, chunk; M unit of that item
+    auto place = [&](int item) {
+        const int tile = item / nmu;
+        lmu = item - tile * nmu;
+        const int tw_i = tile % p.tiles_w, th_i = (tile / p.tiles_w) % p.tiles_h, n = tile / (p.tiles_w * p.tiles_h);
+        const int w0 = tw_i * kW2dCols, h0 = th_i * NW;
+        xg = p.x + (long)n * p.x_sn;
+#pragma unroll
+        for (int e = 0; e < NPP; ++e) {
+            const int piece = wave + NW * e;
+            const int Q = piece * 64 + lane;          // quad (channel c, patch row, quad column) of the stage's patch
+            const int c = Q / PLANEQ, rem = Q - c * PLANEQ;
+            const int row = rem / kW2dPQuads, qd = rem - row * kW2dPQuads;
+            const int hin = h0 - 1 + row, win = w0 - 4 + 4 * qd;
+            const bool ok = piece < PPIECES && rem < PROWS * kW2dPQuads && hin >= 0 && hin < p.H && win >= 0 && win + 4 <= p.W;
+            poff[e] = ok ? 4u * (unsigned)(c * (int)p.x_sc + hin * (int)p.x_sh + win) : kBufOob;
+        }
+    };
+    // profiling only (dev library, AICG_CONV_ABLATE): 1 no DMA, 2 no fragment reads, 4 no patch reads / transform, 8 no MFMAs,
+    // 16 no epilogue, 32 no stage barriers, 64 clocks of workgroup 0 into y[0..1], 128 epilogue without its stores
+    const int dbg = kAblate ? p.dbg : 0;
+    auto issue = [&](float* buf) {                   // the next stage of the walk = (item li, chunk lc) into `buf`
+        if (li >= my_items) return;
+        if (kAblate && (dbg & 1)) { if (++lc == nchunk) { lc = 0; ++li; } return; }
+        if (lc == 0) place(first + slot + li * slots);
+        const long wbase = ((long)lmu * nchunk + lc) * kW2dWFloats;
+        const BufRsrc wb = make_buf(p.w3 + wbase, (unsigned)(kW2dWFloats * 4));
+#pragma unroll
+        for (int e = 0; e < WPW; ++e) {
+            const int piece = wave * WPW + e;
+            w2d_dma16(wb, 16u * (unsigned)lane, 1024u * (unsigned)piece, buf + piece * 256, lane);
+        }
+        const long left = (long)(p.Cin_g - lc * 8) * p.x_sc * 4;   // bytes up to the end of the image's channels: absent channels read 0
+        const BufRsrc xb = make_buf(xg + (long)lc * 8 * p.x_sc, (unsigned)lmin(left, 0x7fffffffL));
+#pragma unroll
+        for (int e = 0; e < NPP; ++e) {
+            const int piece = wave + NW * e;
+            if (piece < PPIECES) w2d_dma16(xb, poff[e], 0u, buf + kW2dWFloats + piece * 256, lane);
+        }
+        if (++lc == nchunk) { lc = 0; ++li; }
+    };
+
+    // ---- the k-step pipeline's registers
+    w2d_f32x4 acc[16][3];
+    float V[16];                                     // B operands of the running k-step, per point
+    float2 raw[4][3];                                // the next k-step's patch as loaded: [patch row][aligned column pair]
+    float N[4][4];                                   // ... on its way to V: R = B^T d, then V = R B in place
+    float ring[PF + 1][3];                           // A fragments: slot pt & PF holds point pt's, fetched PF points ahead
+    float4 aq[3];                                    // AQ: the running point group's fragments per row block (x .. w = points 4 pg .. + 3)
+    // lane-relative LDS offsets: patch (in float2 units: 8-byte reads) = plane of channel ks, patch row 2 (w >> 1), column pair
+    // 16 (w & 1) + l15 -- the aligned pair that starts at input column 2 j - 2; weights (floats) = row l15 of lane group ks
+    const int p_lane2 = ks * PLANEQ * 2 + (2 * (wave >> 1)) * kW2dPQuads * 2 + 1 + 16 * (wave & 1) + l15;
+    const int w_lane = ks * kW2dM + l15;
+    auto load_raw = [&](const float* stage, int s, int r0, int r1) {   // patch rows r0 .. r1 - 1 of k-step s of the stage at `stage`
+        // (stage buffers are 16-byte aligned and every term of the index is a whole float2: 8-byte reads)
+        const float2* pl = reinterpret_cast<const float2*>(__builtin_assume_aligned(stage + kW2dWFloats, 16)) + p_lane2 + s * 4 * PLANEQ * 2;
+#pragma unroll
+        for (int r = r0; r < r1; ++r)
+#pragma unroll
+            for (int h = 0; h < 3; ++h) raw[r][h] = pl[r * kW2dPQuads * 2 + h];
+    };
+    auto rows_to_R = [&](int q0, int q1) {           // columns q0 .. q1 - 1 of B^T d from the loaded patch
+#pragma unroll
+        for (int q = q0; q < q1; ++q) {
+            // input column 2 j - 1 + q = element q + 1 of the six loaded values
+            float d[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d[r] = ((q + 1) & 1) ? raw[r][(q + 1) >> 1].y : raw[r][(q + 1) >> 1].x;
+            N[0][q] = d[0] - d[2];
+            N[1][q] = d[1] + d[2];
+            N[2][q] = d[2] - d[1];
+            N[3][q] = d[1] - d[3];
+        }
+    };
+    auto R_to_V = [&](int i0, int i1) {              // rows i0 .. i1 - 1 of (B^T d) B, in place
+#pragma unroll
+        for (int i = i0; i < i1; ++i) {
+            const float r0 = N[i][0], r1 = N[i][1], r2 = N[i][2], r3 = N[i][3];
+            N[i][0] = r0 - r2;
+            N[i][1] = r1 + r2;
+            N[i][2] = r2 - r1;
+            N[i][3] = r1 - r3;
+        }
+    };
+    auto take_V = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) V[4 * i + q] = N[i][q];
+    };
+    auto fetch_q = [&](const float* stage, int s, int pg, int rb) {      // AQ: row block rb's fragments of point group pg of k-step s
+        if (kAblate && (dbg & 2)) return;
+        aq[rb] = reinterpret_cast<const float4*>(__builtin_assume_aligned(stage, 16))[(s * 4 + pg) * 4 * kW2dM + ks * kW2dM + rb * 16 + l15];
+    };
+    auto fetch_a = [&](const float* stage, int s, int pt, int slot_) {   // fragments of point pt of k-step s of the stage at `stage`
+        if (kAblate && (dbg & 2)) return;
+        const float* wq = stage + (s * 16 + pt) * 4 * kW2dM + w_lane;
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) ring[slot_][rb] = wq[rb * 16];
+    };
+    // One k-step: 16 points x 3 MFMAs on (cur, s) with the operands in V, while the next k-step (stage nxt, k-step index sn) is read,
+    // transformed and its first fragments fetched.  Every point is two scheduling regions: LDS reads (the fragments of point pt + PF,
+    // the raw patch under points 8 and 9), then the point's MFMAs with the VALU of the transform between them -- left to itself hipcc
+    // sinks each fragment read to just in front of the MFMA that consumes it.  The preparation is placed late (the last additions
+    // under point 15) so that its registers are the ones the V values of the points already done leave free: two waves per SIMD leave
+    // a wave 64 registers besides its 192 accumulators.  FIRST: the item's first k-step starts the accumulators.
+    auto kstep = [&](auto first_tag, const float* cur, int s, const float* nxt, int sn) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        if constexpr (AQ) {
+            // twelve steps (point group pg, row block rb) of four MFMAs; the step's fragment quad is reloaded in place right behind
+            // them with the same row block's quad of the next group (next k-step after the last): 8 MFMAs = 256 cycles to land
+#pragma unroll
+            for (int st = 0; st < 12; ++st) {
+                const int pg = st / 3, rb = st - 3 * pg;
+                w2d_fence();
+                if (!(kAblate && (dbg & 4))) {
+                    if (st == 8) rows_to_R(0, 2);
+                    else if (st == 9) rows_to_R(2, 4);
+                    else if (st == 10) R_to_V(0, 2);
+                    else if (st == 11) R_to_V(2, 4);
+                }
+#pragma unroll
+                for (int p4 = 0; p4 < 4; ++p4) {
+                    const int pt = 4 * pg + p4;
+                    const float av = p4 == 0 ? aq[rb].x : p4 == 1 ? aq[rb].y : p4 == 2 ? aq[rb].z : aq[rb].w;
+                    if (kAblate && (dbg & 8)) { if constexpr (FIRST) acc[pt][rb] = w2d_f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
+                    if constexpr (FIRST) {
+                        acc[pt][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, V[pt], w2d_f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    } else {
+                        acc[pt][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, V[pt], acc[pt][rb], 0, 0, 0);
+                    }
+                }
+                w2d_fence();
+                if (pg < 3) fetch_q(cur, s, pg + 1, rb);
+                else fetch_q(nxt, sn, 0, rb);
+                if (!(kAblate && (dbg & 4))) {
+                    if (st == 6 || st == 7) load_raw(nxt, sn, 2 * (st - 6), 2 * (st - 6) + 2);
+                }
+            }
+            take_V();
+            return;
+        }
+#pragma unroll
+        for (int pt = 0; pt < 16; ++pt) {
+            if (pt + PF < 16) fetch_a(cur, s, pt + PF, (pt + PF) & PF);
+            else fetch_a(nxt, sn, pt + PF - 16, (pt + PF) & PF);
+            if (!(kAblate && (dbg & 4))) {
+                if (pt == 8 || pt == 9) load_raw(nxt, sn, 2 * (pt - 8), 2 * (pt - 8) + 2);
+            }
+            w2d_fence();
+            if (!(kAblate && (dbg & 4))) {
+                if (pt >= 10 && pt < 14) rows_to_R(pt - 10, pt - 9);
+                else if (pt == 14) R_to_V(0, 2);
+                else if (pt == 15) R_to_V(2, 4);
+            }
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) {
+                if (kAblate && (dbg & 8)) { if constexpr (FIRST) acc[pt][rb] = w2d_f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
+                if constexpr (FIRST) {
+                    acc[pt][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[pt & PF][rb], V[pt], w2d_f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                } else {
+                    acc[pt][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[pt & PF][rb], V[pt], acc[pt][rb], 0, 0, 0);
+                }
+            }
+            w2d_fence();
+        }
+        take_V();
+    };
+
+    // ---- prologue: stages 0 and 1 in flight, the first k-step's operands by hand
+    float* b_cur = smem;                             // stage g, g + 1 and the one being filled (g + 2): rotate per stage
+    float* b_nxt = smem + STAGE;
+    float* b_fill = smem + 2 * STAGE;
+    issue(b_cur);
+    issue(b_nxt);
+    w2d_dma_wait();
+    lds_barrier();                                   // stages 0, 1 and the bias are in LDS
+    load_raw(b_cur, 0, 0, 4);
+    rows_to_R(0, 4);
+    R_to_V(0, 4);
+    take_V();
+#pragma unroll
+    for (int pt = 0; pt < PF; ++pt) fetch_a(b_cur, 0, pt, pt);
+    if constexpr (AQ) {
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) fetch_q(b_cur, 0, 0, rb);
+    }
+#ifndef AICG_EMULATED
+    long long clk0 = 0, wall0 = 0;
+    if (kAblate && (dbg & 64)) { clk0 = clock64(); wall0 = wall_clock64(); }
+#endif
+    // one stage: barrier (stage g + 1 has landed -- every wave waited for its own DMA before arriving -- and the third buffer is free),
+    // DMA of stage g + 2, the two k-steps, wait for this wave's DMA, rotate the buffers
+    bool first_stage = true;
+    auto stage = [&](auto first_tag) {
+        if (!first_stage && !(kAblate && (dbg & 32))) lds_barrier();
+        first_stage = false;
+        issue(b_fill);
+        kstep(first_tag, b_cur, 0, b_cur, 1);
+        kstep(std::false_type{}, b_cur, 1, b_nxt, 0);
+        w2d_dma_wait();
+        float* t = b_cur; b_cur = b_nxt; b_nxt = b_fill; b_fill = t;
+    };
+    for (int k = 0; k < my_items; ++k) {
+        const int item = first + slot + k * slots;
+        const int tile = item / nmu, mu = item - tile * nmu;
+        stage(std::true_type{});                     // the item's first chunk starts the accumulators (MFMAs on the inline constant 0)
+        for (int c = 1; c < nchunk; ++c) stage(std::false_type{});
+        // ---- epilogue: Y = A^T M A per (row block, register); lane = (tile column l15, channel group ks) holds a 2 x 2 output block
+        // per (row block, register).  Lanes l15 and l15 ^ 1 trade halves (one DPP move each way): the even lane stores the upper row
+        // of both blocks -- four consecutive columns, one 16-byte store --, the odd lane the lower row: 12 stores per lane and item
+        // instead of 24, each wave instruction eight 128-byte runs.
+        if (kAblate && (dbg & 16)) continue;
+        const int tw_i = tile % p.tiles_w, th_i = (tile / p.tiles_w) % p.tiles_h, n = tile / (p.tiles_w * p.tiles_h);
+        const int ho = th_i * NW + 2 * (wave >> 1), wo = tw_i * kW2dCols + 2 * (16 * (wave & 1) + l15);
+        const long y_sc = w2d_opaque(p.y_sc), y_sh = w2d_opaque(p.y_sh);
+        const float* brow = bias_s + w2d_opaque(mu) * kW2dM + 4 * ks;
+        // the whole wave's 2 x 32 columns exist and rows are 16-byte aligned: the straight-line form
+        const bool full = ho + 1 < p.Ho && tw_i * kW2dCols + 32 * (wave & 1) + 32 <= p.Wo && ((p.y_sn | p.y_sc | p.y_sh) & 3) == 0 &&
+                          ((uintptr_t)p.y & 15) == 0;
+        auto body = [&](auto act_tag, auto full_tag) {
+            constexpr int ACT = decltype(act_tag)::value;
+            constexpr bool FULL = decltype(full_tag)::value;
+            const int odd = l15 & 1;
+            float* ybase = p.y + (long)n * p.y_sn + (long)ho * p.y_sh + (FULL ? (long)odd * y_sh + (wo - 2 * odd) : (long)wo);
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) {
+                const float4 bq = *reinterpret_cast<const float4*>(brow + rb * 16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mu * kW2dM + rb * 16 + 4 * ks + r;
+                    const float bm = r == 0 ? bq.x : r == 1 ? bq.y : r == 2 ? bq.z : bq.w;
+                    float Wc[4][2];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        Wc[i][0] = (acc[4 * i][rb][r] + acc[4 * i + 1][rb][r]) + acc[4 * i + 2][rb][r];
+                        Wc[i][1] = (acc[4 * i + 1][rb][r] - acc[4 * i + 2][rb][r]) - acc[4 * i + 3][rb][r];
+                    }
+                    float y00 = ((Wc[0][0] + Wc[1][0]) + Wc[2][0]) + bm, y01 = ((Wc[0][1] + Wc[1][1]) + Wc[2][1]) + bm;
+                    float y10 = ((Wc[1][0] - Wc[2][0]) - Wc[3][0]) + bm, y11 = ((Wc[1][1] - Wc[2][1]) - Wc[3][1]) + bm;
+                    y00 = act_static<ACT>(y00, p.act, p.act_slope);
+                    y01 = act_static<ACT>(y01, p.act, p.act_slope);
+                    y10 = act_static<ACT>(y10, p.act, p.act_slope);
+                    y11 = act_static<ACT>(y11, p.act, p.act_slope);
+                    float* dst = ybase + (long)m * y_sc;
+                    if constexpr (FULL) {
+                        // what the partner needs of this lane: the even lane's lower row, the odd lane's upper row
+                        const float g0 = quad_xor1(odd ? y00 : y10), g1 = quad_xor1(odd ? y01 : y11);
+                        const float4 v = odd ? make_float4(g0, g1, y10, y11) : make_float4(y00, y01, g0, g1);
+                        if (!(kAblate && (dbg & 128))) *reinterpret_cast<float4*>(dst) = v;
+                        else asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+                    } else {
+                        const bool row1 = ho + 1 < p.Ho, col1 = wo + 1 < p.Wo;
+                        if (ho < p.Ho && wo < p.Wo) {
+                            dst[0] = y00;
+                            if (col1) dst[1] = y01;
+                            if (row1) { dst[y_sh] = y10; if (col1) dst[y_sh + 1] = y11; }
+                        }
+                    }
+                }
+            }
+        };
+        if (full) {
+            if (p.act == AICG_ACT_NONE) body(std::integral_constant<int, 0>{}, std::true_type{});
+            else if (p.act == AICG_ACT_RELU) body(std::integral_constant<int, 1>{}, std::true_type{});
+            else body(std::integral_constant<int, 3>{}, std::true_type{});
+        } else {
+            if (p.act == AICG_ACT_NONE) body(std::integral_constant<int, 0>{}, std::false_type{});
+            else if (p.act == AICG_ACT_RELU) body(std::integral_constant<int, 1>{}, std::false_type{});
+            else body(std::integral_constant<int, 3>{}, std::false_type{});
+        }
+    }
+#ifndef AICG_EMULATED
+    if (kAblate && (dbg & 64) && blockIdx.x == 0 && tid == 0) {
+        p.y[0] = (float)(clock64() - clk0);
+        p.y[1] = (float)(wall_clock64() - wall0);
+    }
+#endif
+}
+
+// returns 0 launched, < 0 error, 1 not applicable.  p.w3 must point at the F(2 x 2, 3 x 3) image of ops.winograd2d_image:
+// [Cout / 48][ceil(Cin / 8)][s = 0..1][point 0..15][ks = 0..3][m = 0..47], element = U[48 mu + m][8 chunk + 4 s + ks][point].
+template <int NW, int PF>
+static int launch_conv_w2d(ConvArgs& p, hipStream_t stream) {
+    auto al4 = [](long v) { return (v & 3) == 0; };
+    if (p.Cout_g % kW2dM || (p.W & 3) || !al4(p.x_sn) || !al4(p.x_sc) || !al4(p.x_sh) || ((uintptr_t)p.x & 15) || ((uintptr_t)p.w3 & 15)) return 1;
+    if ((long)8 * p.x_sc + (long)p.H * p.x_sh >= (1L << 29)) return 1;   // 32-bit byte offsets inside an 8-channel slab
+    p.tiles_w = idiv_up(p.Wo, kW2dCols);
+    p.tiles_h = idiv_up(p.Ho, NW);
+    p.nchunk = idiv_up(p.Cin_g, 8);
+    p.Mpad = p.Cout_g / kW2dM;
+    const long nitems = (long)p.N * p.tiles_h * p.tiles_w * p.Mpad;
+    if (nitems > 2147483647L - 8) return fail(AICG_E_SHAPE, "conv: too many output tiles");
+    const size_t lds = (size_t)(kW2dBufs * w2d_stage_floats(NW) + p.Cout_g) * sizeof(float);
+    const int per_xcd = (int)((nitems + 7) >> 3);
+    int slots = 32;                                   // one workgroup per CU
+    if (slots > per_xcd) slots = per_xcd;
+    allow_dynamic_lds((const void*)conv_w2d_kernel<NW, PF>, lds);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_w2d_kernel<NW, PF>), dim3((unsigned)(8 * slots)), dim3(64 * NW), lds, stream, p);
+    return check_launch("conv_w2d_kernel");
+}
+
+int run_w2d_8(ConvArgs& p, hipStream_t st);
+int run_w2d_4(ConvArgs& p, hipStream_t st);
+int run_w2d_8q(ConvArgs& p, hipStream_t st);
+int run_w2d_4q(ConvArgs& p, hipStream_t st);
+
+}  // namespace aicg

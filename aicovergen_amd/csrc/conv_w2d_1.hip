@@ -1,0 +1,8 @@
+// instantiation unit: Winograd F(2 x 2, 3 x 3) 3 x 3 convolution (conv_w2d.h)
+#include "conv_w2d.h"
+namespace aicg {
+int run_w2d_8(ConvArgs& p, hipStream_t st) { return launch_conv_w2d<8, 1>(p, st); }
+int run_w2d_4(ConvArgs& p, hipStream_t st) { return launch_conv_w2d<4, 3>(p, st); }
+int run_w2d_8q(ConvArgs& p, hipStream_t st) { return launch_conv_w2d<8, 0>(p, st); }
+int run_w2d_4q(ConvArgs& p, hipStream_t st) { return launch_conv_w2d<4, 0>(p, st); }
+}  // namespace aicg

@@ -50,7 +50,11 @@ __global__ void __launch_bounds__(256) avgpool2x2_kernel(const float* __restrict
 //   r = s(gi_r + W_hr h + b_hr); z = s(gi_z + W_hz h + b_hz); n = tanh(gi_n + r*(W_hn h + b_hn)); h = (1-z)*n + z*h
 template <int HD, int KR, int KL>
 __global__ void __launch_bounds__(3 * HD / 2) gru_kernel(const float* __restrict__ gi, const float* __restrict__ whh_t,
-                                                         const float* __restrict__ bhh, float* __restrict__ out, long T) {
+                                                         const float* __restrict__ bhh, float* __restrict__ out, long T, long s0, long s1,
+                                                         float* hstate) {
+    // steps s0 .. s1 - 1 of the recurrence (forward: frame s, backward: frame T - 1 - s); hstate (2, HD): the hidden state a later
+    // segment resumes from -- read when s0 > 0, written at the end.  A recurrence cut into segments this way is the same arithmetic
+    // step by step: bit-identical to one launch over 0 .. T.
     // 3*HD/2 threads, two gate rows each (j and j + 3*HD/2): 6 waves for HD = 256 leave each wave a 256-register
     // budget, of which 2*KR hold weights.
     constexpr int NT = 3 * HD / 2;
@@ -74,9 +78,9 @@ __global__ void __launch_bounds__(3 * HD / 2) gru_kernel(const float* __restrict
         wl[k * 3 * HD + j0] = W[(long)(KR + k) * 3 * HD + j0];
         wl[k * 3 * HD + j1] = W[(long)(KR + k) * 3 * HD + j1];
     }
-    if (j0 < HD) h[j0] = 0.f;
+    if (j0 < HD) h[j0] = s0 > 0 ? hstate[dir * HD + j0] : 0.f;
     __syncthreads();
-    for (long s = 0; s < T; ++s) {
+    for (long s = s0; s < s1; ++s) {
         const long t = dir == 0 ? s : T - 1 - s;
         // the input projections of this step are independent of h: issue their loads before the dot products
         float g0 = 0.f, g1 = 0.f, g2 = 0.f;
@@ -119,6 +123,7 @@ __global__ void __launch_bounds__(3 * HD / 2) gru_kernel(const float* __restrict
         }
         __syncthreads();
     }
+    if (hstate && j0 < HD) hstate[dir * HD + j0] = h[j0];
 }
 
 // ---- two-workgroup GRU: all of W_hh on chip ------------------------------------------------------------------------
@@ -259,7 +264,10 @@ __global__ void __launch_bounds__(3 * HD / 2) gru2_kernel(const float* __restric
 template <int HD>
 __global__ void __launch_bounds__(3 * HD / 2) gru4_kernel(const float* __restrict__ gi, const float* __restrict__ whh_t,
                                                           const float* __restrict__ bhh, float* __restrict__ out, long T,
-                                                          unsigned long long* xbuf, int* err, int force_agent) {
+                                                          unsigned long long* xbuf, int* err, int force_agent, long s0, long s1,
+                                                          float* hstate) {
+    // steps s0 .. s1 - 1 (see gru_kernel); the granule tags stay the GLOBAL step number + 1, so the exchange buffer of the previous
+    // segment (tags <= s0) can never satisfy a poll of this one
     constexpr int HQ = HD / 4;      // units per workgroup
     constexpr int NR = 3 * HQ;      // gate rows per workgroup
     constexpr int NT = 2 * NR;      // threads: two per row
@@ -308,11 +316,11 @@ __global__ void __launch_bounds__(3 * HD / 2) gru4_kernel(const float* __restric
         for (int q = 0; q < 16; ++q) wr[kb + q] = W[(long)(kh * KH + kb + q) * 3 * HD + row];
         asm volatile("" ::: "memory");  // 16 loads (and their 64-bit addresses) in flight at a time, not KH
     }
-    if (t_ < HD) h[t_] = 0.f;
+    if (t_ < HD) h[t_] = s0 > 0 ? hstate[dir * HD + t_] : 0.f;
     __syncthreads();
     const int my_unit = part * HQ + u;                  // valid for t_ < HQ (gate 0, column half 0)
     const float* hk = h + kh * KH;
-    for (long s = 0; s < T; ++s) {
+    for (long s = s0; s < s1; ++s) {
         const long t = dir == 0 ? s : T - 1 - s;
         float g0 = 0.f, g1 = 0.f, g2 = 0.f;
         if (t_ < HQ) {
@@ -367,6 +375,7 @@ __global__ void __launch_bounds__(3 * HD / 2) gru4_kernel(const float* __restric
         __syncthreads();
         if ((s & 31) == 31 && *((volatile int*)err)) return;   // a timed-out partner: everybody leaves within 32 steps
     }
+    if (hstate && t_ < HQ) hstate[dir * HD + my_unit] = h[my_unit];   // this workgroup's quarter of the state
 }
 
 // ---- salience decode: RMVPE.to_local_average_cents + decode (rmvpe.py:359-364, 385-409) -----------------------
@@ -466,25 +475,33 @@ extern "C" int aicg_avgpool2x2(const float* x, float* out, int N, int C, int H, 
     return check_launch("avgpool2x2_kernel");
 }
 
-extern "C" int aicg_gru_bidir(const float* gi, const float* whh_t, const float* bhh, float* out, int hidden, int64_t T,
-                              void* stream) {
+extern "C" int aicg_gru_bidir_seg(const float* gi, const float* whh_t, const float* bhh, float* out, int hidden, int64_t T,
+                                  int64_t s_begin, int64_t s_end, float* h_state, void* stream) {
     if (!gi || !whh_t || !bhh || !out) return fail(AICG_E_ARG, "aicg_gru_bidir: null pointer");
-    if (T == 0) return AICG_OK;
+    if (s_begin < 0 || s_end > T || s_begin > s_end || (s_begin > 0 && !h_state))
+        return fail(AICG_E_ARG, "aicg_gru_bidir_seg: steps %ld .. %ld of %ld (a segment that does not start at 0 needs h_state)", (long)s_begin,
+                    (long)s_end, (long)T);
+    if (T == 0 || s_begin == s_end) return AICG_OK;
     if (hidden == 256) {
         constexpr int KR = 96, KL = 48;
         const size_t lds = (size_t)(4 * 256 + KL * 768) * sizeof(float);
         auto kern = gru_kernel<256, KR, KL>;
         allow_dynamic_lds((const void*)kern, lds);
-        hipLaunchKernelGGL(kern, dim3(2), dim3(384), lds, (hipStream_t)stream, gi, whh_t, bhh, out, (long)T);
+        hipLaunchKernelGGL(kern, dim3(2), dim3(384), lds, (hipStream_t)stream, gi, whh_t, bhh, out, (long)T, (long)s_begin, (long)s_end, h_state);
     } else if (hidden == 64) {
         constexpr int KR = 32, KL = 16;
         const size_t lds = (size_t)(4 * 64 + KL * 192) * sizeof(float);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(gru_kernel<64, KR, KL>), dim3(2), dim3(96), lds, (hipStream_t)stream, gi, whh_t, bhh,
-                           out, (long)T);
+                           out, (long)T, (long)s_begin, (long)s_end, h_state);
     } else {
         return fail(AICG_E_SHAPE, "aicg_gru_bidir: hidden size %d not instantiated (256, 64)", hidden);
     }
     return check_launch("gru_kernel");
+}
+
+extern "C" int aicg_gru_bidir(const float* gi, const float* whh_t, const float* bhh, float* out, int hidden, int64_t T,
+                              void* stream) {
+    return aicg_gru_bidir_seg(gi, whh_t, bhh, out, hidden, T, 0, T, nullptr, stream);
 }
 
 extern "C" int aicg_gru_bidir_2wg(const float* gi, const float* whh_t, const float* bhh, float* out, int hidden, int64_t T,
@@ -502,7 +519,7 @@ extern "C" int aicg_gru_bidir_2wg(const float* gi, const float* whh_t, const flo
         const size_t lds = (size_t)(256 + 384 + (256 - KR) * 384) * sizeof(float);
         auto kern = gru2_kernel<256, KR>;
         allow_dynamic_lds((const void*)kern, lds);
-        hipLaunchKernelGGL(kern, dim3(32), dim3(384), lds, (hipStream_t)stream, gi, whh_t, bhh, out, (long)T, xb, err, force_agent);
+        hipLaunchKernelGGL(kern, dim3(32), dim3(384), lds, (hipStream_t)stream, gi, whh_t, bhh, out, (long)T, xb, err, (int)force_agent);
     } else if (hidden == 64) {
         constexpr int KR = 48;
         const size_t lds = (size_t)(64 + 96 + (64 - KR) * 96) * sizeof(float);
@@ -514,15 +531,20 @@ extern "C" int aicg_gru_bidir_2wg(const float* gi, const float* whh_t, const flo
     return check_launch("gru2_kernel");
 }
 
-extern "C" int aicg_gru_bidir_4wg(const float* gi, const float* whh_t, const float* bhh, float* out, int hidden, int64_t T,
-                                  void* xchg_scratch, void* stream) {
+extern "C" int aicg_gru_bidir_4wg_seg(const float* gi, const float* whh_t, const float* bhh, float* out, int hidden, int64_t T,
+                                      int64_t s_begin, int64_t s_end, float* h_state, void* xchg_scratch, void* stream) {
     // xchg_scratch: 2 dirs x 4 parts x 2 parities x hidden/4 granules of 8 bytes (= 32*hidden bytes) + 64 zeroed bytes (error word,
-    // XCC ids) -- the same size as aicg_gru_bidir_2wg's
+    // XCC ids) -- the same size as aicg_gru_bidir_2wg's.  The segments of one recurrence share it: the first (s_begin == 0) clears it,
+    // the following ones only the XCC ids (every launch re-establishes where its workgroups run); the error word accumulates.
     if (!gi || !whh_t || !bhh || !out || !xchg_scratch) return fail(AICG_E_ARG, "aicg_gru_bidir_4wg: null pointer");
     if (hidden != 256) return fail(AICG_E_SHAPE, "aicg_gru_bidir_4wg: hidden size %d not instantiated (256)", hidden);
-    if (T == 0) return AICG_OK;
+    if (s_begin < 0 || s_end > T || s_begin > s_end || (s_begin > 0 && !h_state))
+        return fail(AICG_E_ARG, "aicg_gru_bidir_4wg_seg: steps %ld .. %ld of %ld (a segment that does not start at 0 needs h_state)",
+                    (long)s_begin, (long)s_end, (long)T);
+    if (T == 0 || s_begin == s_end) return AICG_OK;
     const size_t xbytes = (size_t)2 * 4 * 2 * (hidden / 4) * 8;
-    (void)hipMemsetAsync(xchg_scratch, 0, xbytes + 64, (hipStream_t)stream);
+    if (s_begin == 0) (void)hipMemsetAsync(xchg_scratch, 0, xbytes + 64, (hipStream_t)stream);
+    else (void)hipMemsetAsync((char*)xchg_scratch + xbytes + 16, 0, 32, (hipStream_t)stream);
     unsigned long long* xb = (unsigned long long*)xchg_scratch;
     int* err = (int*)((char*)xchg_scratch + xbytes);
     AICG_SWITCH(force_agent, "AICG_GRU_AGENT_STORES", 0);  // A/B switch
@@ -532,8 +554,13 @@ extern "C" int aicg_gru_bidir_4wg(const float* gi, const float* whh_t, const flo
     const unsigned nblocks = 32;
 #endif
     hipLaunchKernelGGL(HIP_KERNEL_NAME(gru4_kernel<256>), dim3(nblocks), dim3(384), 0, (hipStream_t)stream, gi, whh_t, bhh, out, (long)T,
-                       xb, err, (int)force_agent);
+                       xb, err, (int)force_agent, (long)s_begin, (long)s_end, h_state);
     return check_launch("gru4_kernel");
+}
+
+extern "C" int aicg_gru_bidir_4wg(const float* gi, const float* whh_t, const float* bhh, float* out, int hidden, int64_t T,
+                                  void* xchg_scratch, void* stream) {
+    return aicg_gru_bidir_4wg_seg(gi, whh_t, bhh, out, hidden, T, 0, T, nullptr, xchg_scratch, stream);
 }
 
 extern "C" int aicg_salience_decode(const float* salience, double* cents, double* f0, int* center, int64_t T, int n_bins,

@@ -14,6 +14,8 @@ parallel over fixed-size work items, so the only collective is the join:
 With world_size == 1 (or no initialised process group) every function degenerates to the single-GPU path, so the
 same code is exercised by the 1-GPU tests.
 """
+import time
+
 import torch
 import torch.distributed as td
 
@@ -46,8 +48,18 @@ def mdx_separate(mdx_sess, wave, denoise, m_threads=2, group=None):
     if part.shape[0] < per:  # the last rank may own fewer windows: pad to the common block size
         pad = torch.zeros((per - part.shape[0],) + tuple(part.shape[1:]), dtype=part.dtype, device=part.device)
         part = torch.cat([part, pad], 0)
+    t0 = None
+    if ws > 1 and part.is_cuda:   # bench.py's per-rank split: where a multi-GPU step's time goes (own windows done -> join done)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
     allw = all_gather_equal(part, group)[: len(meta["jobs"])]
+    if t0 is not None:
+        torch.cuda.synchronize()
+        last_join["mdx_allgather_s"] = last_join.get("mdx_allgather_s", 0.0) + time.perf_counter() - t0
     return mdx_sess.join_windows(allw, meta)
+
+
+last_join = {}   # seconds this rank spent in the data-path collectives since the caller last cleared it (bench.py reports them per rank)
 
 
 def gather_pieces(pieces, total, device, group=None):

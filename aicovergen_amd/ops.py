@@ -228,6 +228,31 @@ def winograd_kernel(w):
     return torch.stack([g0, (g0 + g1 + g2) * 0.5, (g0 - g1 + g2) * 0.5, g2], -1).contiguous()
 
 
+# The two-dimensional form F(2 x 2, 3 x 3) (csrc/conv_w2d.h): 16 instead of 36 contractions per 2 x 2 output block, for layers whose
+# output channels come in units of 48 (every MDX-Net level).  AICG_WINOGRAD=1 keeps the row-only form everywhere.
+winograd2d = os.environ.get("AICG_WINOGRAD", "2") == "2"
+winograd2d_waves = int(os.environ.get("AICG_W2D_WAVES", "8"))   # 8: two waves per SIMD on an 8 x 64 tile; 4: one per SIMD on 4 x 64
+
+
+winograd2d_quads = os.environ.get("AICG_W2D_QUADS", "0") == "1"   # fragment image: [s][p / 4][ks][m][p % 4] (16-byte fragments)
+
+
+def winograd2d_image(w, quads=False):
+    """(Cout, Cin, 3, 3), Cout % 48 == 0 -> the image aicg_conv_desc.wino == 2 reads (include/aicg.h): U = G g G^T per (co, ci), laid out
+    [Cout / 48][ceil(Cin / 8)][s][point 4 i + q][ks][m] with input channel 8 chunk + 4 s + ks (zero beyond Cin); `quads`:
+    [Cout / 48][ceil(Cin / 8)][s][point / 4][ks][m][point % 4] (wino == 4 / 5)."""
+    co, ci = w.shape[:2]
+    assert co % 48 == 0 and tuple(w.shape[2:]) == (3, 3)
+    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w.device)
+    U = torch.einsum("ia,ocab,jb->ocij", G, w.double(), G).to(torch.float32)          # exact: every factor is a power of two
+    cpad = (ci + 7) // 8 * 8
+    Up = torch.zeros((co, cpad, 16), dtype=torch.float32, device=w.device)
+    Up[:, :ci] = U.reshape(co, ci, 16)
+    if quads:
+        return Up.view(co // 48, 48, cpad // 8, 2, 4, 4, 4).permute(0, 2, 3, 5, 4, 1, 6).contiguous().view(-1)
+    return Up.view(co // 48, 48, cpad // 8, 2, 4, 16).permute(0, 2, 3, 5, 4, 1).contiguous().view(-1)
+
+
 class PackedConv:
     """A convolution layer ready for aicg_conv_forward: packed weights + geometry.  1-D layers use KH=1."""
 
@@ -249,10 +274,13 @@ class PackedConv:
         self.split = bool(split_precision)
         self.w = pack_conv_weight(weight.to(device), groups, self.split)
         self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
-        self.w_wino = None
+        self.w_wino = self.w_wino2 = self.w_wino2q = None
         if (winograd and not self.split and not _fp32_depth and (self.kh, self.kw) == (3, 3) and stride == (1, 1) and dilation == (1, 1)
                 and padding == (1, 1) and self.padding_end is None and groups == 1 and cin_g >= 8):
             self.w_wino = pack_conv_weight(winograd_kernel(weight.detach().to(device=device, dtype=torch.float32)), 1, False)
+            if winograd2d and self.cout % 48 == 0:
+                self.w_wino2 = winograd2d_image(weight.detach().to(device=device, dtype=torch.float32))
+                self.w_wino2q = winograd2d_image(weight.detach().to(device=device, dtype=torch.float32), quads=True)
 
     def out_hw(self, h, w):
         pe = self.padding if self.padding_end is None else self.padding_end
@@ -363,23 +391,26 @@ def conv(x, pc, res=None, out=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NON
     wino = (getattr(pc, "w_wino", None) is not None and not is1d and res is None and not accumulate and pre_act == ACT_NONE
             and out_scale == 1.0 and act in (ACT_NONE, ACT_RELU) and not shuffle and out_len is None and wo % 2 == 0
             and n * ho * wo >= winograd_min_positions)
-    d.wino = 1 if wino else 0
+    # ... its two-dimensional form where the layer has it and the map is float4-aligned
+    wino2 = (wino and winograd2d and getattr(pc, "w_wino2", None) is not None and w % 4 == 0 and x4.stride(0) % 4 == 0 and x4.stride(1) % 4 == 0
+             and x4.stride(2) % 4 == 0 and x4.data_ptr() % 16 == 0)
+    d.wino = ((2 if winograd2d_waves == 8 else 3) + (2 if winograd2d_quads else 0)) if wino2 else 1 if wino else 0
     prof = conv_profile
     if prof is not None and x.is_cuda:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _call("aicg_conv_forward", ctypes.addressof(d), _ptr(x4), _ptr(pc.w_wino if wino else pc.w), _ptr(b), _ptr(r4), _ptr(o4), _stream(x))
+    _call("aicg_conv_forward", ctypes.addressof(d), _ptr(x4), _ptr((pc.w_wino2q if winograd2d_quads else pc.w_wino2) if wino2 else pc.w_wino if wino else pc.w), _ptr(b), _ptr(r4), _ptr(o4), _stream(x))
     if prof is not None and x.is_cuda:
         e1.record()
         prof.events.append((e0, e1))
         prof.flops += 2.0 * n * pc.cout * (pc.cin // pc.groups) * pc.kh * pc.kw * ho * wo
-        prof.flops_executed += 2.0 * n * pc.cout * (pc.cin // pc.groups) * pc.kh * pc.kw * ho * wo * (2.0 / 3.0 if wino else 1.0)
+        prof.flops_executed += 2.0 * n * pc.cout * (pc.cin // pc.groups) * pc.kh * pc.kw * ho * wo * (4.0 / 9.0 if wino2 else 2.0 / 3.0 if wino else 1.0)
         prof.bytes += 4.0 * (n * c * h * w + pc.cout * (pc.cin // pc.groups) * pc.kh * pc.kw
                              + n * pc.cout * ho * wo * (1 + (r4 is not None) + bool(accumulate)))
         prof.launches += 1
         prof.shapes.append(("N%d C%d>%d %dx%d k%dx%d s%d,%d d%d,%d g%d%s%s%s" % (
             n, c, pc.cout, h, w, pc.kh, pc.kw, pc.stride[0], pc.stride[1], pc.dilation[0], pc.dilation[1], pc.groups,
-            " res" if r4 is not None else "", " acc" if accumulate else "", (" shuf" if shuffle else "") + (" wino" if wino else "")),
+            " res" if r4 is not None else "", " acc" if accumulate else "", (" shuf" if shuffle else "") + (" wino2" if wino2 else " wino" if wino else "")),
             2.0 * n * pc.cout * (pc.cin // pc.groups) * pc.kh * pc.kw * ho * wo))
     return out
 
@@ -643,6 +674,44 @@ def gru_bidir(gi, whh_t, bhh, hidden, two_workgroups=None):
         return out
     _call("aicg_gru_bidir", _ptr(gi), _ptr(whh_t), _ptr(bhh), _ptr(out), hidden, t, _stream(gi))
     return out
+
+
+class GruSegments:
+    """The BiGRU recurrence of gru_bidir cut into segments of steps (aicg_gru_bidir*_seg): `run(s0, s1)` queues steps s0 .. s1 - 1 of
+    both directions -- forward frames s0 .. s1 - 1, backward frames T - s1 .. T - s0 - 1 -- on the current stream.  Bit-identical to the
+    one-launch form (the hidden state is carried in fp32); what it buys is that the frames BOTH directions have passed,
+    `ready(s1)` = [T - s1, s1), grow from the middle of the track while the recurrence is still on its way to the ends."""
+
+    def __init__(self, gi, whh_t, bhh, hidden, two_workgroups=None):
+        assert gi.is_contiguous() and gi.shape[0] == 6 * hidden
+        _check(gi, whh_t, bhh)
+        self.gi, self.whh_t, self.bhh, self.hidden, self.T = gi, whh_t, bhh, hidden, gi.shape[1]
+        self.out = torch.empty((2 * hidden, self.T), dtype=torch.float32, device=gi.device)
+        self.state = torch.zeros((2, hidden), dtype=torch.float32, device=gi.device)
+        multi = GRU_TWO_WORKGROUPS if two_workgroups is None else two_workgroups
+        self.multi = bool(multi) and hidden == 256 and GRU_WORKGROUPS == 4     # the four-workgroup kernel; otherwise the single-workgroup one
+        self.scratch = torch.empty(32 * hidden + 64, dtype=torch.uint8, device=gi.device) if self.multi else None
+        self.done = 0
+
+    def run(self, s1):
+        """Queue steps self.done .. s1 - 1."""
+        s0, s1 = self.done, min(int(s1), self.T)
+        if s1 <= s0:
+            return
+        if self.multi:
+            _call("aicg_gru_bidir_4wg_seg", _ptr(self.gi), _ptr(self.whh_t), _ptr(self.bhh), _ptr(self.out), self.hidden, self.T, s0, s1,
+                  _ptr(self.state), _ptr(self.scratch), _stream(self.gi))
+            if s1 == self.T:   # one flag for the whole recurrence (the error word accumulates over the segments)
+                _gru_pending.append((self.scratch[32 * self.hidden: 32 * self.hidden + 4].view(torch.int32),
+                                     (self.gi, self.whh_t, self.bhh, self.out, self.hidden)))
+        else:
+            _call("aicg_gru_bidir_seg", _ptr(self.gi), _ptr(self.whh_t), _ptr(self.bhh), _ptr(self.out), self.hidden, self.T, s0, s1,
+                  _ptr(self.state), _stream(self.gi))
+        self.done = s1
+
+    def ready(self):
+        """[lo, hi): frames whose forward AND backward state exist after the steps queued so far (empty: lo >= hi)."""
+        return max(0, self.T - self.done), min(self.T, self.done)
 
 
 def salience_decode(salience, thred=0.03, want_center=False):

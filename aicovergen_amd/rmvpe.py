@@ -205,6 +205,32 @@ class E2E:
         return sal[0].t().contiguous().unsqueeze(0)                      # (1, T, 360)
 
 
+    def progressive(self, mel, n_frames, nseg, on_ready, two_workgroups=None, group=None):
+        """__call__ with the recurrence in `nseg` segments (ops.GruSegments): after each one, `on_ready(lo, hi, salience)` is called for
+        the frame ranges [lo, hi) < n_frames that BOTH directions have now passed -- the track's middle first, its ends last -- with
+        their (hi - lo, 360) salience rows; everything is queued on the current stream.  Same arithmetic per frame as __call__ (the
+        classifier is a per-frame GEMM; the dispatcher may tile a short range differently, i.e. another fp32 summation order)."""
+        T = mel.shape[-1]
+        feat = (self.features(mel) if group is None else self.features_sharded(mel, group)).unsqueeze(0)
+        gi = ops.conv(feat, self.gru_in)
+        seg = ops.GruSegments(gi[0], self.whh_t, self.bhh, self.hidden, two_workgroups)
+        step = ((T + nseg - 1) // nseg + 31) // 32 * 32
+        lo_prev = hi_prev = None
+        for k in range(nseg):
+            seg.run((k + 1) * step)
+            lo, hi = seg.ready()
+            if lo >= hi:
+                continue
+            new = [(lo, hi)] if lo_prev is None else [(lo, lo_prev), (hi_prev, hi)]
+            lo_prev, hi_prev = lo, hi
+            for a, b in new:
+                b = min(b, n_frames)
+                if a < b:
+                    sal = ops.conv(seg.out[:, a:b].unsqueeze(0), self.fc, act=ops.ACT_SIGMOID)      # (1, 360, b - a)
+                    on_ready(a, b, sal[0].t().contiguous())
+        return seg
+
+
 class RMVPE:
     def __init__(self, model_path, is_half, device=None, state_dict=None):
         self.resample_kernel = {}
@@ -247,6 +273,20 @@ class RMVPE:
         mel = self.mel_extractor(audio, center=True)
         hidden = self.mel2hidden(mel, two_workgroups, group)
         return self._decode_device(hidden[0], thred)[1]
+
+    def infer_progressive(self, audio, thred, nseg, on_f0, two_workgroups=None, group=None):
+        """infer_from_audio_device with the recurrence in `nseg` segments: `on_f0(lo, hi, f0)` receives the float64 f0 of frames
+        [lo, hi) as soon as both GRU directions have passed them (middle of the track first), queued on the current stream.
+        -> number of frames."""
+        if not torch.is_tensor(audio):
+            audio = torch.from_numpy(np.asarray(audio))
+        audio = audio.float().to(self.device).unsqueeze(0)
+        mel = self.mel_extractor(audio, center=True)
+        n_frames = mel.shape[-1]
+        mel = F.pad(mel, (0, 32 * ((n_frames - 1) // 32 + 1) - n_frames), mode="reflect")
+        self.model.progressive(mel, n_frames, nseg, lambda a, b, sal: on_f0(a, b, self._decode_device(sal, thred)[1]),
+                               two_workgroups, group)
+        return n_frames
 
     def infer_from_audio(self, audio, thred=0.03, group=None):
         f0 = self.infer_from_audio_device(audio, thred, group=group).cpu().numpy()

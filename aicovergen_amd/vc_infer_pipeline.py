@@ -29,6 +29,21 @@ input_audio_path2wav = {}
 _NO_GROUP = "single"   # sentinel understood by dist.world(): this call must not communicate even if a process group exists
 
 
+class _HostStream:
+    """What the overlapped schedule needs of a torch.cuda.Stream when the kernels run synchronously on the host (the CPU emulator
+    of tests/): every hand-over is already ordered."""
+
+    def wait_stream(self, other): pass
+    def wait_event(self, ev): pass
+    def synchronize(self): pass
+    def __enter__(self): return self
+    def __exit__(self, *a): return False
+
+
+class _HostEvent:
+    def record(self, stream=None): pass
+
+
 def _rms_frames(y, frame_length, hop_length):
     """librosa.feature.rms(y=y, frame_length=, hop_length=) of librosa 0.9.1: center=True with reflect padding,
     frame power mean, sqrt; returns (1, n_frames) float32 like librosa does for float32 input."""
@@ -407,15 +422,20 @@ class VC(object):
         # stream on top of them; the synthesizer passes start once both are done.  Everything is enqueued from this thread
         # (a helper thread fights the launch loop for the GIL).  AICG_OVERLAP_F0=0 restores the reference's serial order
         # (f0, then per chunk: features, synthesis).
-        overlap = (if_f0 == 1 and f0_method == "rmvpe" and self._sync()
+        on_gpu = self._sync()
+        # (AICG_F0_SEGMENTS on the host: the CPU tests walk the same progressive schedule, with the streams and events as no-ops)
+        nseg = int(os.environ.get("AICG_F0_SEGMENTS", "0")) or (16 if world > 1 else 0)
+        overlap = (if_f0 == 1 and f0_method == "rmvpe" and (on_gpu or nseg > 1)
                    and os.environ.get("AICG_OVERLAP_F0", "1") != "0")
         feats_of = {}
         f0_wait = 0.0
+        marks = []            # progressive f0: (first frame, end frame, event) -- the frame range whose pitch exists once the event has fired
+        progressive = False
         if overlap:
-            main = torch.cuda.current_stream(self.device)
+            main = torch.cuda.current_stream(self.device) if on_gpu else _HostStream()
             # one side stream per VC object: the caching allocator keeps a block pool per stream, a fresh stream per call
             # would strand RMVPE's working set (a few GB for a 4-minute track) in up to 32 pools
-            side = getattr(self, "_f0_stream", None)
+            side = getattr(self, "_f0_stream", None) if on_gpu else _HostStream()
             if side is None:
                 # high priority: the f0 branch is a short U-Net followed by a 70 ms recurrence on four CUs; dispatched first it
                 # leaves the chip to HuBERT while the GRU runs, dispatched behind HuBERT's launches it finishes 40 ms later
@@ -427,20 +447,46 @@ class VC(object):
             pad_dev = audio_pad.float()
             side.wait_stream(main)
             tf0 = ttime()
-            with torch.cuda.stream(side):
-                f0_dev = self._rmvpe().infer_from_audio_device(pad_dev, thred=0.03, group=self._rmvpe_group())
+            # Progressive f0 (multi-GPU: every rank runs the whole-track BiGRU, N x 32 ms for N x 240 s): the recurrence is queued in
+            # segments, and the pitch of a frame range exists as soon as BOTH directions have passed it -- the middle of the track at
+            # half the recurrence time, its ends last.  The chunk loop below then takes this rank's chunks middle-out and waits per
+            # chunk (events), not for the whole track.  Same values as the one-launch form (GruSegments); the host never sees f0.
+            progressive = nseg > 1 and inp_f0 is None
+            if progressive:
+                f0_mel_min, f0_mel_max = 1127 * np.log(1 + 50 / 700), 1127 * np.log(1 + 1100 / 700)
+                pitch = torch.ones((1, p_len), dtype=torch.long, device=self.device)
+                pitchf = torch.zeros((1, p_len), dtype=torch.float32, device=self.device)
+                cover = [p_len, 0]
+
+                def on_f0(lo, hi, f0, _factor=pow(2, f0_up_key / 12)):
+                    f0bak, coarse = ops.f0_coarse(f0, _factor, f0_mel_min, f0_mel_max)
+                    hi2 = min(hi, p_len)
+                    if lo < hi2:
+                        pitch[0, lo:hi2] = coarse[: hi2 - lo]
+                        pitchf[0, lo:hi2] = f0bak[: hi2 - lo].float()
+                    cover[0], cover[1] = min(cover[0], lo), max(cover[1], hi2)
+                    ev = torch.cuda.Event() if on_gpu else _HostEvent()
+                    ev.record(side)
+                    marks.append((cover[0], cover[1], ev))
+
+                with (torch.cuda.stream(side) if on_gpu else side):
+                    self._rmvpe().infer_progressive(pad_dev, 0.03, nseg, on_f0, group=self._rmvpe_group())
+            else:
+                with (torch.cuda.stream(side) if on_gpu else side):
+                    f0_dev = self._rmvpe().infer_from_audio_device(pad_dev, thred=0.03, group=self._rmvpe_group())
             many = self._vc_features_many(model, [pad_dev[bounds[ci][0]:bounds[ci][1]] for ci in mine], index, big_npy, index_rate,
                                           version, use_protect)
             feats_of = dict(zip(mine, many))
             main.synchronize()
             tf1 = ttime()
-            side.synchronize()
-            main.wait_stream(side)
-            f0_host = f0_dev.cpu().numpy()
-            if ops.gru_timed_out():  # two-workgroup GRU starved of its partner under the HuBERT load: single-workgroup rerun
-                f0_host = self._rmvpe().infer_from_audio_device(pad_dev, thred=0.03, two_workgroups=False).cpu().numpy()
-            pitch, pitchf = run_f0(f0_host)
-            del f0_dev
+            if not progressive:
+                side.synchronize()
+                main.wait_stream(side)
+                f0_host = f0_dev.cpu().numpy()
+                if ops.gru_timed_out():  # multi-workgroup GRU starved of its partners under the HuBERT load: single-workgroup rerun
+                    f0_host = self._rmvpe().infer_from_audio_device(pad_dev, thred=0.03, two_workgroups=False).cpu().numpy()
+                pitch, pitchf = run_f0(f0_host)
+                del f0_dev
             t2 = ttime()
             f0_wait = t2 - tf1
             times[0] += tf1 - tf0
@@ -454,6 +500,19 @@ class VC(object):
             times[1] += t2 - t1
         pieces = {}
 
+        def frames_of(ci):
+            s, e = bounds[ci]
+            return s // self.window, (p_len if ci == len(bounds) - 1 else (e - self.window) // self.window)
+
+        def mark_of(ci):      # index of the first mark whose range covers the chunk's frames
+            fa, fb = frames_of(ci)
+            for m, (lo, hi, _) in enumerate(marks):
+                if lo <= fa and min(fb, p_len) <= hi:
+                    return m
+            return len(marks) - 1
+
+        order = sorted(mine, key=lambda ci: (mark_of(ci), ci)) if progressive else list(mine)
+
         def chunk_pitch(ci):
             s, e = bounds[ci]
             if if_f0 != 1:
@@ -463,7 +522,7 @@ class VC(object):
 
         # Overlapped schedule: the encoder half of chunk i + 1 (text encoder + flow: a few hundred short launches that leave most
         # CUs idle) is queued on a second stream underneath the vocoder of chunk i.  AICG_OVERLAP_SYNTH=0: one stream.
-        two_streams = overlap and hasattr(net_g, "infer_front") and os.environ.get("AICG_OVERLAP_SYNTH", "1") != "0"
+        two_streams = overlap and on_gpu and hasattr(net_g, "infer_front") and os.environ.get("AICG_OVERLAP_SYNTH", "1") != "0"
         fronts = {}
         if two_streams:
             main = torch.cuda.current_stream(self.device)
@@ -476,6 +535,8 @@ class VC(object):
                 s, e = bounds[ci]
                 pc, pcf = chunk_pitch(ci)
                 feats, feats0 = feats_of.pop(ci)
+                if progressive:
+                    enc.wait_event(marks[mark_of(ci)][2])      # this chunk's pitch frames exist
                 with torch.cuda.stream(enc):
                     noise = noise_fn(ci, s, e) if noise_fn is not None else None
                     st = self._vc_synth_front(net_g, sid, e - s, feats, feats0, pc, pcf, protect, noise)
@@ -484,35 +545,65 @@ class VC(object):
                 # the inputs stay referenced until the chunk's synchronize below: nothing is recycled under the other stream
                 fronts[ci] = (st, ev, (feats, feats0, pc, pcf, noise))
 
-            if mine:
-                queue_front(mine[0])
-        for k, ci in enumerate(mine):
+            if order:
+                queue_front(order[0])
+
+        def drain():          # the chunk's work is done (progressive: without waiting for the f0 stream's remaining segments)
+            if not on_gpu:
+                return
+            if progressive:
+                torch.cuda.current_stream(self.device).synchronize()
+            else:
+                torch.cuda.synchronize()
+
+        for k, ci in enumerate(order):
             s, e = bounds[ci]
             pc, pcf = chunk_pitch(ci)
             if two_streams:
                 ts0 = ttime()
-                if k + 1 < len(mine):
-                    queue_front(mine[k + 1])
+                if k + 1 < len(order):
+                    queue_front(order[k + 1])
                 st, ev, keep = fronts.pop(ci)
                 main.wait_event(ev)
                 out = self._vc_synth_back(net_g, st)[0, 0]
-                torch.cuda.synchronize()
+                drain()
                 del st, keep
                 times[2] += ttime() - ts0
             elif overlap:
                 noise = noise_fn(ci, s, e) if noise_fn is not None else None
                 ts0 = ttime()
                 feats, feats0 = feats_of.pop(ci)
+                if progressive and on_gpu:
+                    torch.cuda.current_stream(self.device).wait_event(marks[mark_of(ci)][2])
                 out = self._vc_synth(net_g, sid, e - s, feats, feats0, pc, pcf, protect, noise)[0, 0]
-                torch.cuda.synchronize()
+                drain()
                 times[2] += ttime() - ts0
             else:
                 noise = noise_fn(ci, s, e) if noise_fn is not None else None
                 out = self.vc(model, net_g, sid, audio_pad[s:e], pc, pcf, times, index, big_npy, index_rate, version, protect,
                               noise=noise, keep_on_device=True)
             pieces[ci] = out[self.t_pad_tgt: -self.t_pad_tgt]
+        if progressive:
+            if on_gpu:
+                torch.cuda.synchronize()
+            if ops.gru_timed_out():
+                # the multi-workgroup recurrence starved of its partners (a busy or shared GPU): this rank's f0 is invalid.  Recompute
+                # it locally on the single-workgroup kernel (no collective: the other ranks may be fine) and redo this rank's chunks
+                f0_host = self._rmvpe().infer_from_audio_device(audio_pad.float(), thred=0.03, two_workgroups=False).cpu().numpy()
+                pitch, pitchf = run_f0(f0_host)
+                many = self._vc_features_many(model, [audio_pad.float()[bounds[ci][0]:bounds[ci][1]] for ci in mine], index, big_npy,
+                                              index_rate, version, use_protect)
+                for ci, (feats, feats0) in zip(mine, many):
+                    s, e = bounds[ci]
+                    pc, pcf = chunk_pitch(ci)
+                    noise = noise_fn(ci, s, e) if noise_fn is not None else None
+                    out = self._vc_synth(net_g, sid, e - s, feats, feats0, pc, pcf, protect, noise)[0, 0]
+                    pieces[ci] = out[self.t_pad_tgt: -self.t_pad_tgt]
+                if on_gpu:
+                    torch.cuda.synchronize()
         tc1 = ttime()
         pieces = adist.gather_pieces(pieces, len(bounds), self.device, group)
+        tj1 = ttime()
         audio_opt = torch.cat([pieces[i] for i in range(len(bounds))]).contiguous()
         if resample_sr >= 16000 and tgt_sr != resample_sr:
             # optional output resampling (rvc_infer passes resample_sr=0): host fallback, not on the hot path
@@ -535,7 +626,8 @@ class VC(object):
         # wall-clock split of this call (host pre-processing, f0, chunk loop, join + host post-processing)
         # (overlapped schedule: f0_s = features of every chunk with the f0 branch underneath, f0_wait_s of it spent waiting for f0)
         self.last_profile = {"plan_s": t1 - tp0, "f0_s": t2 - t1, "chunks_s": tc1 - t2, "post_s": ttime() - tc1,
-                             "f0_wait_s": f0_wait, "overlap_f0": float(bool(overlap))}
+                             "f0_wait_s": f0_wait, "overlap_f0": float(bool(overlap)), "join_s": tj1 - tc1,
+                             "f0_progressive": float(bool(progressive))}
         return audio_opt
 
 

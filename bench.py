@@ -90,6 +90,7 @@ def one_step(config, mdxs, vc, hub, net_g, wave44_dev, group, emu=False):
     from aicovergen_amd import dist as adist
     from aicovergen_amd import ops
     t0 = time.perf_counter()
+    adist.last_join.clear()
     sep = wave44_dev
     for i, m in enumerate(mdxs):   # main.py feeds each separation the previous one's stem; run_mdx peak-normalises its input
         if i > 0:
@@ -99,7 +100,7 @@ def one_step(config, mdxs, vc, hub, net_g, wave44_dev, group, emu=False):
         torch.cuda.synchronize()  # stage boundary (the reference writes the stems to disk here)
     mdx_s = time.perf_counter() - t0
     if config == "C2":
-        return sep, None, [0, 0, 0], {"mdx_s": mdx_s}
+        return sep, None, [0, 0, 0], dict(adist.last_join, mdx_s=mdx_s)
     t1 = time.perf_counter()
     wave16 = ops.resample_poly_mono(sep, 44100, 16000)      # stereo 44.1 kHz -> mono 16 kHz, stays in HBM
     if not emu:
@@ -108,7 +109,7 @@ def one_step(config, mdxs, vc, hub, net_g, wave44_dev, group, emu=False):
     method = "mangio-crepe" if config == "C4" else "rmvpe"
     out = vc.pipeline(hub, net_g, 0, wave16, "synthetic.wav", times, 0, method, "", 0.5, 1, 3, vc.t_pad_tgt // vc.x_pad, 0, 0.25,
                       "v2", 0.33, 128, group=group, noise_seed=1234)
-    return sep, out, times, dict(vc.last_profile, mdx_s=mdx_s, resample_s=time.perf_counter() - t1 - sum(
+    return sep, out, times, dict(vc.last_profile, mdx_s=mdx_s, **adist.last_join, resample_s=time.perf_counter() - t1 - sum(
         vc.last_profile[k] for k in ("plan_s", "f0_s", "chunks_s", "post_s")))
 
 
@@ -149,7 +150,7 @@ def pmc_traffic_per_launch():
     """HBM bytes per conv launch from the committed rocprofv3 PMC passes of this same command (profiles/r03_summary.json, falling
     back to earlier rounds): FETCH_SIZE (x 2: the gfx950 under-report for wide reads, MI355X_MICROARCH.md) + WRITE_SIZE, KiB units, summed
     over the conv kernels; None when no summary is committed.  The counters cannot be collected inside the timed run."""
-    for tag in ("r03", "r02", "r01"):
+    for tag in ("r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_summary.json" % tag)
         try:
             s = json.load(open(path))
@@ -164,8 +165,9 @@ def pmc_traffic_per_launch():
 
 def stage_table(conv, stages, steps):
     """Per-stage roofline fractions (report per stage; STFT / iSTFT stand-alone)."""
-    rows = [{"stage": "conv family (implicit GEMM)", "bound": "mfma", "ms_per_step": conv["ms"] / steps,
-             "achieved": conv["tflops"], "unit": "TFLOP/s", "frac": conv["tflops"] / MFMA_PEAK}]
+    rows = [{"stage": "conv family (implicit GEMM + Winograd)", "bound": "mfma", "ms_per_step": conv["ms"] / steps,
+             "achieved": conv["tflops"], "executed": conv["tflops_executed"], "unit": "TFLOP/s",
+             "frac": conv["tflops_executed"] / MFMA_PEAK, "frac_algorithmic": conv["tflops"] / MFMA_PEAK}]
     for name, r in sorted(stages.items(), key=lambda kv: -kv[1]["ms"]):
         if r["ms"] <= 0:
             continue
@@ -341,6 +343,16 @@ def main():
         td.all_gather(allt, dts)
         per_rank = [float(t.item()) for t in allt]
     dt = max(per_rank)                                   # MAX over ranks
+    # where each rank's step went (seconds per step): own MDX windows incl. the stem all-gather, the all-gather alone, plan, HuBERT
+    # with the f0 branch underneath, the wait for f0 behind it, the chunk loop, the chunk join, post -- so that a scaling curve says
+    # which term grew
+    split_keys = ["mdx_s", "mdx_allgather_s", "plan_s", "f0_s", "f0_wait_s", "chunks_s", "join_s", "post_s"]
+    per_rank_split = None
+    if world > 1:
+        mine_split = torch.tensor([split.get(k, 0.0) for k in split_keys], dtype=torch.float64, device=device)
+        alls = [torch.empty_like(mine_split) for _ in range(world)]
+        td.all_gather(alls, mine_split)
+        per_rank_split = [dict(zip(split_keys, [round(float(v), 5) for v in t.cpu().tolist()])) for t in alls]
     if rank == 0:
         ms = dt / args.steps * 1e3
         x = (vc.x_pad, vc.x_query, vc.x_center, vc.x_max) if vc is not None else None
@@ -367,6 +379,7 @@ def main():
                        "sharding": "mdx windows + rvc chunks + rmvpe u-net time segments over %d rank(s), all-gather joins; the rmvpe bigru is "
                                    "one recurrence over the track, computed on every rank" % world,
                        "per_rank_seconds_per_step": [t / args.steps for t in per_rank],
+                       "per_rank_wall_split_seconds_per_step": per_rank_split,
                        "stage_seconds_per_step": {"hubert": stage[0] / args.steps, "f0": stage[1] / args.steps,
                                                   "synth": stage[2] / args.steps},
                        "wall_split_seconds_per_step": split,
@@ -376,16 +389,21 @@ def main():
             conv = prof.summary()
             traffic = None if split_mode else pmc_traffic_per_launch()   # the committed PMC passes are of the default (fp32) command
             res["roofline"] = {
+                # `achieved` is what SURVEY 8(d) defines: every layer's DIRECT-form flops over the family's kernel time.  The Winograd
+                # layers execute 4/9 (two-dimensional form) or 2/3 (row form) of those multiply-adds, so `achieved` is an effective
+                # rate and may exceed the peak; the fraction of the matrix pipe's roofline is `frac` = executed / peak.
                 "bound": "mfma", "achieved": conv["tflops"], "peak": MFMA_PEAK, "unit": "TFLOP/s",
-                "frac": conv["tflops"] / MFMA_PEAK,
+                "frac": conv["tflops_executed"] / MFMA_PEAK,
+                "frac_algorithmic": conv["tflops"] / MFMA_PEAK,
                 "traffic": None if traffic is None else traffic["fetch_x2"],
                 "traffic_unit": None if traffic is None else
                 "HBM bytes per launch: rocprofv3 2 x FETCH_SIZE + WRITE_SIZE (%s); uncorrected %.4g" % (traffic["source"],
                                                                                                        traffic["raw"]),
                 "executed": conv["tflops_executed"],
-                "executed_note": "TFLOP/s the matrix pipe was given: the 3x3 TFC layers of MDX-Net run the Winograd F(2,3)-along-rows "
-                                 "kernel (conv_ws3w), 2/3 of the algorithmic multiply-adds; `achieved` counts every layer's direct-form flops",
-                "kernel": "conv family (fp32 MFMA: conv_ws3 / conv_ws3m16h implicit GEMM, conv_ws3w Winograd F(2,3))" if not split_mode
+                "executed_note": "TFLOP/s the matrix pipe was given: the 3x3 TFC layers of MDX-Net run the Winograd F(2x2,3x3) kernel "
+                                 "(conv_w2d: 16 instead of 36 multiply-adds per 2x2 output block; AICG_WINOGRAD=1: the F(2,3)-along-rows "
+                                 "kernel conv_ws3w, 2/3); `achieved` counts every layer's direct-form flops, `frac` = executed / peak",
+                "kernel": "conv family (fp32 MFMA: conv_ws3 / conv_ws3m16h implicit GEMM, conv_w2d Winograd F(2x2,3x3))" if not split_mode
                 else "conv family (split precision: conv_ws3s on the bf16 MFMA, 3 MFMAs per product -- achieved and peak are "
                      "in fp32-equivalent TFLOP/s, peak = 2516.6 / 3; the f0 models' layers run the fp32 kernels)",
                 "measured": "HIP events around every launch of one extra step of the same work, taken right behind the timed "

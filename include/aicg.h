@@ -123,7 +123,12 @@ typedef struct aicg_conv_desc {
                                      stride 1, dilation 1, padding 1, groups 1 layer -- U[.][.][kh][0..3] = (g0, (g0 + g1 + g2) / 2,
                                      (g0 - g1 + g2) / 2, g2) of row kh -- and the layer runs csrc/conv_ws3w.h (12 instead of 18
                                      contractions per output pair).  Needs packed_v3, no residual / accumulate / shuffle /
-                                     pre-activation, act none or ReLU, out_scale 1 */
+                                     pre-activation, act none or ReLU, out_scale 1.
+                                     2: the two-dimensional form F(2 x 2, 3 x 3) (csrc/conv_w2d.h: 16 instead of 36 contractions per
+                                     2 x 2 output block) of the same kind of layer; w_packed is ONE image,
+                                     [Cout / 48][ceil(Cin / 8)][s = 0..1][point p = 4 i + q][ks = 0..3][m = 0..47] floats with element
+                                     U[48 mu + m][8 chunk + 4 s + ks][i][q], U = G g G^T, G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]
+                                     (zero beyond Cin).  Needs Cout % 48 == 0, W % 4 == 0, x 16-byte aligned with strides % 4 == 0 */
 } aicg_conv_desc;
 
 int aicg_conv_bkc(int taps);
@@ -219,6 +224,16 @@ int aicg_gru_bidir_2wg(const float* gi, const float* whh_t, const float* bhh, fl
  * aicg_gru_bidir_2wg (the exchange-timeout word is the first int behind the 32 * hidden granule bytes). */
 int aicg_gru_bidir_4wg(const float* gi, const float* whh_t, const float* bhh, float* out, int hidden, int64_t T,
                        void* xchg_scratch, void* stream);
+/* The recurrence in SEGMENTS: steps s_begin .. s_end - 1 of the T (the forward direction visits frame s, the backward one frame
+ * T - 1 - s), resuming from / leaving its hidden state in h_state (2, hidden) (may be NULL for a segment that starts at 0 and is not
+ * continued).  Cut this way the recurrence is the same arithmetic step by step -- bit-identical to one call over 0 .. T -- but the
+ * frames both directions have passed become available segment by segment: the multi-GPU pipeline starts synthesising the middle
+ * chunks of a track while the recurrence (replicated on every rank) still runs towards its ends.  The segments of one
+ * recurrence share xchg_scratch (cleared by the segment that starts at 0). */
+int aicg_gru_bidir_seg(const float* gi, const float* whh_t, const float* bhh, float* out, int hidden, int64_t T, int64_t s_begin,
+                       int64_t s_end, float* h_state, void* stream);
+int aicg_gru_bidir_4wg_seg(const float* gi, const float* whh_t, const float* bhh, float* out, int hidden, int64_t T, int64_t s_begin,
+                           int64_t s_end, float* h_state, void* xchg_scratch, void* stream);
 /* RMVPE.decode / to_local_average_cents (src/rmvpe.py:359-364,385-409).  salience: (T, n_bins) row-major fp32;
  * cents, f0: (T) float64 (bit-equal to the numpy reference given identical salience); center: (T) argmax or NULL. */
 int aicg_salience_decode(const float* salience, double* cents, double* f0, int* center, int64_t T, int n_bins,

@@ -46,6 +46,24 @@ def test_committed_bench_lines_follow_the_contract(path):
         assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
 
 
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(ROOT, "profiles", "r04_bench_*.json"))))
+def test_round4_lines_report_the_executed_fraction(path):
+    """Round 4: `achieved` stays SURVEY 8(d)'s algorithmic rate (direct-form flops / kernel time: an effective rate that the
+    Winograd layers can push past the peak), `frac` is the fraction of the matrix pipe's roofline -- executed / peak, never above 1 --
+    and `frac_algorithmic` = achieved / peak rides along."""
+    d = json.loads(open(path).read())
+    for k in TOP:
+        assert k in d, k
+    assert abs(d["value"] - d["config"]["audio_seconds_total"] * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert abs(r["frac"] - r["executed"] / r["peak"]) < 1e-9 and abs(r["frac_algorithmic"] - r["achieved"] / r["peak"]) < 1e-9
+    assert 0 < r["frac"] < 1 and r["executed"] <= r["achieved"] + 1e-9
+    for s in d["stages"]:
+        assert s["bound"] in ("mfma", "hbm") and 0 < s["frac"] < 1
+    if d["n_gpus"] > 1:
+        assert len(d["config"]["per_rank_wall_split_seconds_per_step"]) == d["n_gpus"]
+
+
 def test_default_line_has_the_cpu_baseline():
     d = json.loads(open(os.path.join(ROOT, "profiles", "r03_bench_c3_default.json")).read())
     assert d["config"]["config_id"] == "C3" and d["dtype"] == "f32" and "cpu_baseline" in d and d["roofline"]["traffic"] > 0
@@ -59,13 +77,14 @@ def test_default_line_has_the_cpu_baseline():
 
 def test_stage_table_and_traffic_helpers():
     b = _bench()
-    conv = {"ms": 800.0, "tflops": 100.0}
+    conv = {"ms": 800.0, "tflops": 150.0, "tflops_executed": 100.0}
     stages = {"tdf_gemm_nt": {"ms": 100.0, "flops": 1e13, "bytes": 0.0}, "stft": {"ms": 4.0, "flops": 0.0, "bytes": 1.4e9},
               "unused": {"ms": 0.0, "flops": 0.0, "bytes": 0.0}}
     rows = b.stage_table(conv, stages, 2)
-    assert [r["stage"] for r in rows] == ["conv family (implicit GEMM)", "tdf_gemm_nt", "stft"]
-    assert rows[0]["ms_per_step"] == 400.0 and abs(rows[0]["frac"] - 100.0 / 157.3) < 1e-12
+    assert [r["stage"] for r in rows] == ["conv family (implicit GEMM + Winograd)", "tdf_gemm_nt", "stft"]
+    assert rows[0]["ms_per_step"] == 400.0 and abs(rows[0]["frac"] - 100.0 / 157.3) < 1e-12          # executed / peak
+    assert abs(rows[0]["frac_algorithmic"] - 150.0 / 157.3) < 1e-12 and rows[0]["achieved"] == 150.0
     assert rows[1]["unit"] == "TFLOP/s" and abs(rows[1]["achieved"] - 100.0) < 1e-9
     assert rows[2]["bound"] == "hbm" and abs(rows[2]["achieved"] - 350.0) < 1e-9
     t = b.pmc_traffic_per_launch()
-    assert t is not None and t["fetch_x2"] > t["raw"] > 0 and t["source"].startswith("profiles/r03")
+    assert t is not None and t["fetch_x2"] > t["raw"] > 0 and t["source"].startswith("profiles/r0")

@@ -105,6 +105,7 @@ def test_conv2d_winograd_rows(dev, monkeypatch, n, ci, co, H, W, act):
     column tiles (interior ones take 16-byte patch loads) and channel chunks, output written into a channel slice.  Same products up to the exact 1/2 of G; the sums of the
     transformed operands round differently from the direct form, hence 2e-6 rather than bit equality."""
     monkeypatch.setattr(ops, "winograd_min_positions", 1)
+    monkeypatch.setattr(ops, "winograd2d", False)          # the row form (the two-dimensional one: test_conv2d_winograd_2d)
     torch.manual_seed(H * W + ci)
     x = torch.randn(n, ci, H, W)
     w = torch.randn(co, ci, 3, 3) * 0.1
@@ -122,13 +123,61 @@ def test_conv2d_winograd_rows(dev, monkeypatch, n, ci, co, H, W, act):
     assert rel_rms(y, ref + r) < 1e-5
 
 
+@pytest.mark.parametrize("waves", [8, 4])
+@pytest.mark.parametrize("n,ci,co,H,W,act", [(1, 8, 48, 8, 64, ops.ACT_RELU), (2, 16, 48, 11, 72, ops.ACT_NONE), (1, 24, 96, 5, 132, ops.ACT_RELU),
+                                              (1, 12, 48, 17, 60, ops.ACT_RELU), (3, 40, 144, 3, 8, ops.ACT_NONE), (1, 48, 48, 16, 196, ops.ACT_RELU)])
+def test_conv2d_winograd_2d(dev, monkeypatch, waves, n, ci, co, H, W, act):
+    """F(2 x 2, 3 x 3) (csrc/conv_w2d.h) on TFC-shaped layers, in both workgroup forms: one and several M units of 48 channels, input
+    channels that are not a multiple of the 8-channel chunk (zeros from the buffer range check / the padded image), odd row counts
+    (a row pair whose second row does not exist), ragged and sub-tile widths (multiples of 4), several tiles per workgroup in the
+    persistent walk, several images, output written into a channel slice.  Same products up to the exact 1/2 and 1/4 of G g G^T; the
+    sums of the transformed operands round differently from the direct form, hence 2e-6 rather than bit equality."""
+    monkeypatch.setattr(ops, "winograd_min_positions", 1)
+    monkeypatch.setattr(ops, "winograd2d", True)
+    monkeypatch.setattr(ops, "winograd2d_waves", waves)
+    torch.manual_seed(H * W + ci)
+    x = torch.randn(n, ci, H, W)
+    w = torch.randn(co, ci, 3, 3) * 0.1
+    b = torch.randn(co)
+    pc = ops.PackedConv(w, b, padding=1, device=dev.device)
+    assert pc.w_wino2 is not None
+    prof = ops.conv_profile = ops.ConvProfile()
+    try:
+        buf = dev.t(torch.full((n, co + 3, H, W), 7.0))
+        ops.conv(dev.t(x), pc, act=act, out=buf[:, 2:2 + co])
+    finally:
+        ops.conv_profile = None
+    ref = F.conv2d(x, w, b, padding=1)
+    assert rel_rms(buf[:, 2:2 + co], F.relu(ref) if act == ops.ACT_RELU else ref) < 2e-6
+    assert (buf[:, :2] == 7).all() and (buf[:, 2 + co:] == 7).all()
+    # a width that is not a multiple of 4 cannot be staged by 16-byte DMA: the row form takes the layer
+    x2 = torch.randn(1, ci, 6, 66)
+    y2 = ops.conv(dev.t(x2), pc, act=act)
+    r2 = F.conv2d(x2, w, b, padding=1)
+    assert rel_rms(y2, F.relu(r2) if act == ops.ACT_RELU else r2) < 2e-6
+
+
+def test_winograd2d_image_layout():
+    """ops.winograd2d_image against a literal loop over the definition in include/aicg.h."""
+    torch.manual_seed(0)
+    w = torch.randn(96, 11, 3, 3)
+    img = ops.winograd2d_image(w).view(2, 2, 2, 16, 4, 48)
+    G = torch.tensor([[1.0, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1.0]])
+    for (mu, ch, s, pnt, ks, m) in [(0, 0, 0, 0, 0, 0), (1, 1, 0, 5, 2, 47), (0, 1, 1, 15, 3, 13), (1, 0, 1, 9, 1, 30)]:
+        ci = 8 * ch + 4 * s + ks
+        want = (G @ w[48 * mu + m, ci] @ G.t())[pnt // 4, pnt % 4] if ci < 11 else torch.tensor(0.0)
+        assert torch.allclose(img[mu, ch, s, pnt, ks, m], want, atol=1e-6)
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", ["rows", "2d8", "2d4"])
 @pytest.mark.parametrize("n,c,h,w", [(2, 48, 256, 3072), (2, 96, 128, 1536), (6, 144, 64, 768), (2, 192, 32, 384), (2, 240, 16, 192)])
-def test_winograd_at_mdx_level_sizes(n, c, h, w):
-    """The Winograd forms at the real MDX-Net level shapes (every tile kind; batch 6 on the 144-channel level so that the map has
-    >= 1024 four-row tiles and the 96 + 48-row split really runs on hardware -- ADVICE r3; interior 16-byte patch loads; the
-    persistent walk over > 1 tile per workgroup), against (a) the direct HIP kernels over the whole map and (b) torch's fp32
-    convolution on the host over two sub-maps -- the top-left corner and the bottom-right one, all output channels, so padding,
+def test_winograd_at_mdx_level_sizes(n, c, h, w, form):
+    """The Winograd forms -- F(2, 3) along rows (conv_ws3w.h) and F(2 x 2, 3 x 3) with eight or four waves (conv_w2d.h) -- at the
+    real MDX-Net level shapes (every tile kind; batch 6 on the 144-channel level so that the map has >= 1024 four-row tiles and the
+    row form's 96 + 48-row split really runs on hardware -- ADVICE r3; interior 16-byte patch loads; the persistent walks over > 1
+    tile per workgroup; 1 .. 5 M units of 48 channels), against (a) the direct HIP kernels over the whole map and (b) torch's
+    fp32 convolution on the host over two sub-maps -- the top-left corner and the bottom-right one, all output channels, so padding,
     ragged last tiles and every channel tile are covered by an independent reference."""
     import conftest
     conftest._bind("hip")
@@ -137,23 +186,24 @@ def test_winograd_at_mdx_level_sizes(n, c, h, w):
     wt = torch.randn(c, c, 3, 3) * 0.05
     bias = torch.randn(c) * 0.1
     pc = ops.PackedConv(wt, bias, padding=1, device="cuda")
-    assert pc.w_wino is not None
-    old = ops.winograd_min_positions
+    assert pc.w_wino is not None and pc.w_wino2 is not None
+    old = ops.winograd_min_positions, ops.winograd2d, ops.winograd2d_waves
     try:
         ops.winograd_min_positions = 1 << 60
         ref = ops.conv(x, pc, act=ops.ACT_RELU)
         ops.winograd_min_positions = 1
+        ops.winograd2d, ops.winograd2d_waves = form != "rows", 4 if form == "2d4" else 8
         got = ops.conv(x, pc, act=ops.ACT_RELU)
     finally:
-        ops.winograd_min_positions = old
+        ops.winograd_min_positions, ops.winograd2d, ops.winograd2d_waves = old
     assert not torch.equal(got, ref)          # a different summation order: the other kernel really ran
     e_direct = rel_rms(got, ref)
     rh, rw = min(h, 10), min(w, 72)
     xc = x.cpu()
-    tl = F.relu(F.conv2d(xc[:, :, :rh + 1, :rw + 1], wt, bias, padding=1))[:, :, :rh, :rw]
-    br = F.relu(F.conv2d(xc[:, :, h - rh - 1:, w - rw - 1:], wt, bias, padding=1))[:, :, 1:, 1:]
+    tl = F.relu(F.conv2d(F.pad(xc[:, :, :rh + 1, :rw + 1], (1, 0, 1, 0)), wt, bias))[:, :, :rh, :rw]
+    br = F.relu(F.conv2d(F.pad(xc[:, :, h - rh - 1:, w - rw - 1:], (0, 1, 0, 1)), wt, bias))
     e_tl, e_br = rel_rms(got[:, :, :rh, :rw], tl), rel_rms(got[:, :, h - rh:, w - rw:], br)
-    print("winograd C%d %dx%d: vs direct HIP %.2e, vs torch fp32 corner maps %.2e / %.2e" % (c, h, w, e_direct, e_tl, e_br))
+    print("winograd %s C%d %dx%d: vs direct HIP %.2e, vs torch fp32 corner maps %.2e / %.2e" % (form, c, h, w, e_direct, e_tl, e_br))
     assert e_direct < 4e-6 and e_tl < 4e-6 and e_br < 4e-6
 
 

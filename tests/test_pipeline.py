@@ -130,6 +130,36 @@ def test_resample_sr_branch_vs_reference_golden(dev):
     assert diff.max() <= 3 and (diff <= 1).mean() >= 0.999
 
 
+def test_progressive_f0_schedule_is_bit_identical(dev, monkeypatch):
+    """Multi-GPU schedule: the BiGRU recurrence in segments (AICG_F0_SEGMENTS; on by default for world > 1), the pitch of
+    a frame range published as soon as both directions have passed it, the chunks taken middle-out with a per-chunk wait.  On a
+    6-chunk track the int16 output must equal the one-launch schedule's bit for bit, and the chunk order must really differ."""
+    nets = weights.small_model_set(1234)
+    audio = vocal_like(6.3, 16000, 1239)
+    ref, _, vc0 = run(dev, nets, audio)
+    assert vc0.last_profile["f0_progressive"] == 0.0
+    monkeypatch.setenv("AICG_F0_SEGMENTS", "6")
+    vc, hub, net_g, tgt_sr = build(dev, nets, (1, 1, 1, 2))
+    seen = []
+    orig = vc._vc_synth_front
+
+    def spy(net, sid, n_samples, *a, **k):
+        seen.append(n_samples)
+        return orig(net, sid, n_samples, *a, **k)
+    vc._vc_synth_front = spy
+    out = vc.pipeline(hub, net_g, 0, audio, "x.wav", [0, 0, 0], 0, "rmvpe", "", 0.5, 1, 3, tgt_sr, 0, 0.25, "v2", 0.33, 128,
+                      noise_fn=noise_fn_for(nets))
+    assert vc.last_profile["f0_progressive"] == 1.0
+    if dev.kind == "emu":
+        assert np.array_equal(out, ref)
+    else:   # on the hardware the classifier GEMM over a frame range may take other tiles than over the whole track (fp32 summation order)
+        diff = np.abs(out.astype(np.int32) - ref.astype(np.int32))
+        assert diff.max() <= 3 and (diff <= 1).mean() >= 0.999
+    _, audio_pad, opt_ts, _ = vc.plan(audio)
+    bounds = vc.chunk_bounds(audio_pad, opt_ts)
+    assert len(bounds) >= 5 and seen != [e - s for s, e in bounds] and sorted(seen) == sorted(e - s for s, e in bounds)
+
+
 def assert_bins_agree(coarse, f0, want_coarse, want_f0, want_salience, max_rate=0.002):
     """The C1 test's criterion: coarse-pitch bins equal to the oracle's on >= 99.8 % of the frames; every other frame
     is listed with its f0 distance and the oracle's top-1 - top-2 salience margin and must be a neighbouring bin (a cents value
