@@ -160,6 +160,11 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
             // 2: eight waves (two per SIMD) on an 8 x 64 tile; 3: four waves (one per SIMD) on a 4 x 64 tile; 4 / 5: the same with the
             // quad-fragment image ([s][p / 4][ks][m][p % 4]: one 16-byte fragment read per four MFMAs)
             hipStream_t st2 = (hipStream_t)stream;
+            if (w2d_ablate && d->wino == 2) {
+                const int ra = run_w2d_ablation(p, st2, (int)w2d_ablate);
+                if (ra != 1) return ra;
+                return fail(AICG_E_ARG, "aicg_conv_forward: AICG_CONV_ABLATE=%ld is not an instantiated variant of conv_w2d (or not the dev library)", (long)w2d_ablate);
+            }
             const int rc = d->wino == 2 ? run_w2d_8(p, st2) : d->wino == 3 ? run_w2d_4(p, st2) : d->wino == 4 ? run_w2d_8q(p, st2) : run_w2d_4q(p, st2);
             if (rc == 1)
                 return fail(AICG_E_ARG, "aicg_conv_forward: wino 2 needs Cout %% 48 == 0, W %% 4 == 0, 16-byte aligned x with strides %% 4 == 0");

@@ -44,7 +44,6 @@ static constexpr int kW2dCols = 64;                               // output colu
 static constexpr int kW2dPQuads = (kW2dCols + 8) / 4;             // 18: patch columns w0 - 4 .. w0 + 67
 static constexpr int kW2dWFloats = 2 * 16 * 4 * kW2dM;            // 6144 floats of weights per chunk
 static constexpr int kW2dWPieces = kW2dWFloats / 256;             // 24 DMA pieces (1 KiB) of weights per chunk
-static constexpr int kW2dBufs = 3;
 // quads per channel plane of the patch: (NW + 2) rows of 18, rounded up to 8 mod 16
 __host__ __device__ constexpr int w2d_plane_quads(int nw) { return ((nw + 2) * kW2dPQuads + 7) / 16 * 16 + 8; }
 __host__ __device__ constexpr int w2d_stage_floats(int nw) { return kW2dWFloats + 8 * w2d_plane_quads(nw) * 4; }
@@ -92,8 +91,13 @@ __device__ inline T w2d_opaque(T v) {   // a per-item copy of a uniform value th
 
 // PF: points a fragment is fetched ahead (dword fragments: weights [s][p][ks][m]); PF == 0: QUAD fragments -- weights
 // [s][p / 4][ks][m][p % 4], one ds_read_b128 per (point group, row block) feeding four MFMAs, reloaded in place behind them.
-template <int NW, int PF>
+// ABL: profiling variants, instantiated in the dev library only (tools/kbench_w2d_ablate.py): 1 no DMA, 2 no fragment reads, 4 no patch
+// reads / transform, 8 no MFMAs, 16 no epilogue, 32 no stage barriers, 64 clocks of workgroup 0 into y[0..1], 128 epilogue without its
+// stores.  Compile-time: a run-time switch in the k-step loop costs the 8-wave form its register budget.
+template <int NW, int PF, int ABL = 0>
 __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
+    constexpr int dbg = ABL;
+    constexpr int BUFS = 3;                          // stage g computes, stage g + 1 has landed (k-step (g, 1) reads ahead into it), stage g + 2 is being filled
     static_assert(PF == 0 || PF == 1 || PF == 3, "the fragment ring has PF + 1 slots and 16 points are a whole number of turns");
     constexpr bool AQ = PF == 0;
     constexpr int NT = 64 * NW;
@@ -104,9 +108,19 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
     static_assert(8 * PLANEQ % 64 == 0 && kW2dWPieces % NW == 0, "pieces are whole");
     HIP_DYNAMIC_SHARED(float4, smem4)
     float* const smem = reinterpret_cast<float*>(smem4);
-    float* const bias_s = smem + kW2dBufs * STAGE;   // Cout: the layer's bias
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, ks = lane >> 4;
+    float* const bias_s = smem + BUFS * STAGE;       // Cout: the layer's bias
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, and said so: everything derived from it lives in SGPRs
+    // Per-lane constants are RE-DERIVED from the thread id wherever they are used instead of being kept: besides its 192 accumulators a
+    // wave of the eight-wave form has 64 registers, and a value the compiler spills comes back through scratch memory -- a VMEM load
+    // whose s_waitcnt vmcnt(0) also waits for every DMA piece issued before it.
+    auto lane_now = [&]() __attribute__((always_inline)) {
+        int t = threadIdx.x & 63;
+#ifndef AICG_EMULATED
+        asm volatile("" : "+v"(t));
+#endif
+        return t;
+    };
     const int nmu = p.Mpad;                          // M units (launch_conv_w2d stores Cout / 48 here)
     const int nchunk = p.nchunk;
     // persistent walk: item = tile * nmu + mu; XCD x owns a contiguous eighth of the item list, its workgroups take it `slots` at a time
@@ -120,37 +134,43 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
 
     for (int i = tid; i < nmu * kW2dM; i += NT) bias_s[i] = p.bias ? p.bias[i] : 0.f;
 
-    // ---- DMA plan of this wave: weight pieces w WPW .. + WPW - 1, patch pieces w, w + NW, ...  Only the byte offsets of the patch quads
-    // stay in registers: what a lane fetches of a piece is decoded again per item (a hundred VALU operations against ~40 000 MFMA cycles)
+    // ---- DMA plan of this wave: weight pieces w WPW .. + WPW - 1, patch pieces w, w + NW, ...  What a lane fetches of a patch piece --
+    // quad (channel c, patch row, quad column) -- is the same for every tile: decoded once into LDS (c << 16 | row << 8 | column, or ~0
+    // for an unused slot); per item the byte offsets are rebuilt from it, again into LDS ([piece][thread] dwords behind the bias).
     constexpr int WPW = kW2dWPieces / NW;            // weight pieces per wave (3 / 6)
     constexpr int NPP = (PPIECES + NW - 1) / NW;     // patch pieces per wave (3 / 4)
-    unsigned poff[NPP];
+    unsigned* const tab_s = reinterpret_cast<unsigned*>(bias_s + ((nmu * kW2dM + 3) & ~3));   // [2][NPP][NT]: decode, then offsets
+#pragma unroll
+    for (int e = 0; e < NPP; ++e) {
+        const int piece = wave + NW * e;
+        const int Q = piece * 64 + (tid & 63);
+        const int c = Q / PLANEQ, rem = Q - c * PLANEQ;
+        const int row = rem / kW2dPQuads, qd = rem - row * kW2dPQuads;
+        tab_s[e * NT + tid] = (piece < PPIECES && rem < PROWS * kW2dPQuads) ? (unsigned)(c << 16 | row << 8 | qd) : 0xffffffffu;
+    }
     const float* xg = p.x;
     int li = 0, lc = 0, lmu = 0;                     // DMA cursor: item of this workgroup, chunk; M unit of that item
-    auto place = [&](int item) {
+    auto place = [&](int item) __attribute__((always_inline)) {
         const int tile = item / nmu;
         lmu = item - tile * nmu;
         const int tw_i = tile % p.tiles_w, th_i = (tile / p.tiles_w) % p.tiles_h, n = tile / (p.tiles_w * p.tiles_h);
         const int w0 = tw_i * kW2dCols, h0 = th_i * NW;
         xg = p.x + (long)n * p.x_sn;
+        unsigned* tl = tab_s + wave * 64 + lane_now();
 #pragma unroll
         for (int e = 0; e < NPP; ++e) {
-            const int piece = wave + NW * e;
-            const int Q = piece * 64 + lane;          // quad (channel c, patch row, quad column) of the stage's patch
-            const int c = Q / PLANEQ, rem = Q - c * PLANEQ;
-            const int row = rem / kW2dPQuads, qd = rem - row * kW2dPQuads;
+            const unsigned dcd = tl[e * NT];
+            const int c = (int)(dcd >> 16), row = (int)((dcd >> 8) & 255u), qd = (int)(dcd & 255u);
             const int hin = h0 - 1 + row, win = w0 - 4 + 4 * qd;
-            const bool ok = piece < PPIECES && rem < PROWS * kW2dPQuads && hin >= 0 && hin < p.H && win >= 0 && win + 4 <= p.W;
-            poff[e] = ok ? 4u * (unsigned)(c * (int)p.x_sc + hin * (int)p.x_sh + win) : kBufOob;
+            const bool ok = dcd != 0xffffffffu && hin >= 0 && hin < p.H && win >= 0 && win + 4 <= p.W;
+            tl[(NPP + e) * NT] = ok ? 4u * (unsigned)(c * (int)p.x_sc + hin * (int)p.x_sh + win) : kBufOob;
         }
     };
-    // profiling only (dev library, AICG_CONV_ABLATE): 1 no DMA, 2 no fragment reads, 4 no patch reads / transform, 8 no MFMAs,
-    // 16 no epilogue, 32 no stage barriers, 64 clocks of workgroup 0 into y[0..1], 128 epilogue without its stores
-    const int dbg = kAblate ? p.dbg : 0;
-    auto issue = [&](float* buf) {                   // the next stage of the walk = (item li, chunk lc) into `buf`
+    auto issue = [&](float* buf) __attribute__((always_inline)) {   // the next stage of the walk = (item li, chunk lc) into `buf`: one burst
         if (li >= my_items) return;
-        if (kAblate && (dbg & 1)) { if (++lc == nchunk) { lc = 0; ++li; } return; }
+        if constexpr ((dbg & 1) != 0) { if (++lc == nchunk) { lc = 0; ++li; } return; }
         if (lc == 0) place(first + slot + li * slots);
+        const int lane = lane_now();
         const long wbase = ((long)lmu * nchunk + lc) * kW2dWFloats;
         const BufRsrc wb = make_buf(p.w3 + wbase, (unsigned)(kW2dWFloats * 4));
 #pragma unroll
@@ -160,10 +180,11 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
         }
         const long left = (long)(p.Cin_g - lc * 8) * p.x_sc * 4;   // bytes up to the end of the image's channels: absent channels read 0
         const BufRsrc xb = make_buf(xg + (long)lc * 8 * p.x_sc, (unsigned)lmin(left, 0x7fffffffL));
+        const unsigned* tl = tab_s + NPP * NT + wave * 64 + lane;
 #pragma unroll
         for (int e = 0; e < NPP; ++e) {
             const int piece = wave + NW * e;
-            if (piece < PPIECES) w2d_dma16(xb, poff[e], 0u, buf + kW2dWFloats + piece * 256, lane);
+            if (piece < PPIECES) w2d_dma16(xb, tl[e * NT], 0u, buf + kW2dWFloats + piece * 256, lane);
         }
         if (++lc == nchunk) { lc = 0; ++li; }
     };
@@ -177,9 +198,16 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
     float4 aq[3];                                    // AQ: the running point group's fragments per row block (x .. w = points 4 pg .. + 3)
     // lane-relative LDS offsets: patch (in float2 units: 8-byte reads) = plane of channel ks, patch row 2 (w >> 1), column pair
     // 16 (w & 1) + l15 -- the aligned pair that starts at input column 2 j - 2; weights (floats) = row l15 of lane group ks
-    const int p_lane2 = ks * PLANEQ * 2 + (2 * (wave >> 1)) * kW2dPQuads * 2 + 1 + 16 * (wave & 1) + l15;
-    const int w_lane = ks * kW2dM + l15;
-    auto load_raw = [&](const float* stage, int s, int r0, int r1) {   // patch rows r0 .. r1 - 1 of k-step s of the stage at `stage`
+    int p_lane2 = 0, w_lane = 0, l15 = 0, ks = 0;
+    auto lane_offsets = [&]() __attribute__((always_inline)) {                      // (re-derived at the top of every stage, see lane_now)
+        const int lane = lane_now();
+        l15 = lane & 15;
+        ks = lane >> 4;
+        p_lane2 = ks * PLANEQ * 2 + (2 * (wave >> 1)) * kW2dPQuads * 2 + 1 + 16 * (wave & 1) + l15;
+        w_lane = ks * kW2dM + l15;
+    };
+    lane_offsets();
+    auto load_raw = [&](const float* stage, int s, int r0, int r1) __attribute__((always_inline)) {   // patch rows r0 .. r1 - 1 of k-step s of the stage at `stage`
         // (stage buffers are 16-byte aligned and every term of the index is a whole float2: 8-byte reads)
         const float2* pl = reinterpret_cast<const float2*>(__builtin_assume_aligned(stage + kW2dWFloats, 16)) + p_lane2 + s * 4 * PLANEQ * 2;
 #pragma unroll
@@ -187,7 +215,7 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
 #pragma unroll
             for (int h = 0; h < 3; ++h) raw[r][h] = pl[r * kW2dPQuads * 2 + h];
     };
-    auto rows_to_R = [&](int q0, int q1) {           // columns q0 .. q1 - 1 of B^T d from the loaded patch
+    auto rows_to_R = [&](int q0, int q1) __attribute__((always_inline)) {           // columns q0 .. q1 - 1 of B^T d from the loaded patch
 #pragma unroll
         for (int q = q0; q < q1; ++q) {
             // input column 2 j - 1 + q = element q + 1 of the six loaded values
@@ -200,7 +228,7 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
             N[3][q] = d[1] - d[3];
         }
     };
-    auto R_to_V = [&](int i0, int i1) {              // rows i0 .. i1 - 1 of (B^T d) B, in place
+    auto R_to_V = [&](int i0, int i1) __attribute__((always_inline)) {              // rows i0 .. i1 - 1 of (B^T d) B, in place
 #pragma unroll
         for (int i = i0; i < i1; ++i) {
             const float r0 = N[i][0], r1 = N[i][1], r2 = N[i][2], r3 = N[i][3];
@@ -210,18 +238,18 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
             N[i][3] = r1 - r3;
         }
     };
-    auto take_V = [&]() {
+    auto take_V = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q) V[4 * i + q] = N[i][q];
     };
-    auto fetch_q = [&](const float* stage, int s, int pg, int rb) {      // AQ: row block rb's fragments of point group pg of k-step s
-        if (kAblate && (dbg & 2)) return;
+    auto fetch_q = [&](const float* stage, int s, int pg, int rb) __attribute__((always_inline)) {      // AQ: row block rb's fragments of point group pg of k-step s
+        if constexpr ((dbg & 2) != 0) return;
         aq[rb] = reinterpret_cast<const float4*>(__builtin_assume_aligned(stage, 16))[(s * 4 + pg) * 4 * kW2dM + ks * kW2dM + rb * 16 + l15];
     };
-    auto fetch_a = [&](const float* stage, int s, int pt, int slot_) {   // fragments of point pt of k-step s of the stage at `stage`
-        if (kAblate && (dbg & 2)) return;
+    auto fetch_a = [&](const float* stage, int s, int pt, int slot_) __attribute__((always_inline)) {   // fragments of point pt of k-step s of the stage at `stage`
+        if constexpr ((dbg & 2) != 0) return;
         const float* wq = stage + (s * 16 + pt) * 4 * kW2dM + w_lane;
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) ring[slot_][rb] = wq[rb * 16];
@@ -232,8 +260,9 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
     // sinks each fragment read to just in front of the MFMA that consumes it.  The preparation is placed late (the last additions
     // under point 15) so that its registers are the ones the V values of the points already done leave free: two waves per SIMD leave
     // a wave 64 registers besides its 192 accumulators.  FIRST: the item's first k-step starts the accumulators.
-    auto kstep = [&](auto first_tag, const float* cur, int s, const float* nxt, int sn) {
+    auto kstep = [&](auto first_tag, auto prep_tag, const float* cur, int s, const float* nxt, int sn) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr bool PREP = decltype(prep_tag)::value;     // read and transform the next k-step's patch, fetch its first fragments
         if constexpr (AQ) {
             // twelve steps (point group pg, row block rb) of four MFMAs; the step's fragment quad is reloaded in place right behind
             // them with the same row block's quad of the next group (next k-step after the last): 8 MFMAs = 256 cycles to land
@@ -241,7 +270,7 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
             for (int st = 0; st < 12; ++st) {
                 const int pg = st / 3, rb = st - 3 * pg;
                 w2d_fence();
-                if (!(kAblate && (dbg & 4))) {
+                if constexpr ((dbg & 4) == 0 && PREP) {
                     if (st == 8) rows_to_R(0, 2);
                     else if (st == 9) rows_to_R(2, 4);
                     else if (st == 10) R_to_V(0, 2);
@@ -251,7 +280,7 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
                 for (int p4 = 0; p4 < 4; ++p4) {
                     const int pt = 4 * pg + p4;
                     const float av = p4 == 0 ? aq[rb].x : p4 == 1 ? aq[rb].y : p4 == 2 ? aq[rb].z : aq[rb].w;
-                    if (kAblate && (dbg & 8)) { if constexpr (FIRST) acc[pt][rb] = w2d_f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
+                    if constexpr ((dbg & 8) != 0) { if constexpr (FIRST) acc[pt][rb] = w2d_f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
                     if constexpr (FIRST) {
                         acc[pt][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, V[pt], w2d_f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                     } else {
@@ -260,30 +289,30 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
                 }
                 w2d_fence();
                 if (pg < 3) fetch_q(cur, s, pg + 1, rb);
-                else fetch_q(nxt, sn, 0, rb);
-                if (!(kAblate && (dbg & 4))) {
+                else if constexpr (PREP) fetch_q(nxt, sn, 0, rb);
+                if constexpr ((dbg & 4) == 0 && PREP) {
                     if (st == 6 || st == 7) load_raw(nxt, sn, 2 * (st - 6), 2 * (st - 6) + 2);
                 }
             }
-            take_V();
+            if constexpr (PREP) take_V();
             return;
         }
 #pragma unroll
         for (int pt = 0; pt < 16; ++pt) {
             if (pt + PF < 16) fetch_a(cur, s, pt + PF, (pt + PF) & PF);
-            else fetch_a(nxt, sn, pt + PF - 16, (pt + PF) & PF);
-            if (!(kAblate && (dbg & 4))) {
+            else if constexpr (PREP) fetch_a(nxt, sn, pt + PF - 16, (pt + PF) & PF);
+            if constexpr ((dbg & 4) == 0 && PREP) {
                 if (pt == 8 || pt == 9) load_raw(nxt, sn, 2 * (pt - 8), 2 * (pt - 8) + 2);
             }
             w2d_fence();
-            if (!(kAblate && (dbg & 4))) {
+            if constexpr ((dbg & 4) == 0 && PREP) {
                 if (pt >= 10 && pt < 14) rows_to_R(pt - 10, pt - 9);
                 else if (pt == 14) R_to_V(0, 2);
                 else if (pt == 15) R_to_V(2, 4);
             }
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) {
-                if (kAblate && (dbg & 8)) { if constexpr (FIRST) acc[pt][rb] = w2d_f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
+                if constexpr ((dbg & 8) != 0) { if constexpr (FIRST) acc[pt][rb] = w2d_f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
                 if constexpr (FIRST) {
                     acc[pt][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[pt & PF][rb], V[pt], w2d_f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                 } else {
@@ -292,53 +321,90 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
             }
             w2d_fence();
         }
-        take_V();
+        if constexpr (PREP) take_V();
     };
 
-    // ---- prologue: stages 0 and 1 in flight, the first k-step's operands by hand
+    // ---- prologue: stages 0 and 1 in flight (BUFS == 2: stage 0), the first k-step's operands by hand
     float* b_cur = smem;                             // stage g, g + 1 and the one being filled (g + 2): rotate per stage
     float* b_nxt = smem + STAGE;
-    float* b_fill = smem + 2 * STAGE;
+    float* b_fill = smem + (BUFS - 1) * STAGE;
+    auto open_kstep = [&](const float* stage_) __attribute__((always_inline)) {     // operands of k-step 0 of the stage at `stage_`, without anything to hide behind
+        load_raw(stage_, 0, 0, 4);
+        rows_to_R(0, 4);
+        R_to_V(0, 4);
+        take_V();
+#pragma unroll
+        for (int pt = 0; pt < PF; ++pt) fetch_a(stage_, 0, pt, pt);
+        if constexpr (AQ) {
+#pragma unroll
+            for (int rb = 0; rb < 3; ++rb) fetch_q(stage_, 0, 0, rb);
+        }
+    };
     issue(b_cur);
     issue(b_nxt);
     w2d_dma_wait();
-    lds_barrier();                                   // stages 0, 1 and the bias are in LDS
-    load_raw(b_cur, 0, 0, 4);
-    rows_to_R(0, 4);
-    R_to_V(0, 4);
-    take_V();
-#pragma unroll
-    for (int pt = 0; pt < PF; ++pt) fetch_a(b_cur, 0, pt, pt);
-    if constexpr (AQ) {
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) fetch_q(b_cur, 0, 0, rb);
-    }
+    lds_barrier();                                   // the first stage(s) and the bias are in LDS
 #ifndef AICG_EMULATED
     long long clk0 = 0, wall0 = 0;
-    if (kAblate && (dbg & 64)) { clk0 = clock64(); wall0 = wall_clock64(); }
+    if constexpr ((dbg & (64 | 256)) != 0) { clk0 = clock64(); wall0 = wall_clock64(); }
 #endif
-    // one stage: barrier (stage g + 1 has landed -- every wave waited for its own DMA before arriving -- and the third buffer is free),
-    // DMA of stage g + 2, the two k-steps, wait for this wave's DMA, rotate the buffers
+    int tr_n = 2;
+    auto stamp = [&]() __attribute__((always_inline)) {                             // ABL bit 256: this wave's timeline (workgroup 0, thread 0) into y[2 ..]
+#ifndef AICG_EMULATED
+        if constexpr ((dbg & 256) != 0) {
+            if (blockIdx.x == 0 && tid == 0 && tr_n < 8192) p.y[tr_n++] = (float)(clock64() - clk0);
+        }
+#endif
+    };
+    // one stage: barrier (the stage(s) ahead have landed -- every wave waited for its own DMA before arriving -- and the buffer to fill
+    // is free), DMA of the stage BUFS - 1 ahead, the two k-steps, wait for this wave's DMA, rotate the buffers
+    // The pipeline runs WITHIN an item: its last k-step prepares nothing, so that no operand of the k-step pipeline is live across the
+    // epilogue (whose temporaries would push it into scratch memory), and the next item opens with open_kstep.
     bool first_stage = true;
-    auto stage = [&](auto first_tag) {
-        if (!first_stage && !(kAblate && (dbg & 32))) lds_barrier();
+    auto stage = [&](auto first_tag, auto last_tag) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr bool LAST = decltype(last_tag)::value;
+        stamp();
+        if (!first_stage && (dbg & 32) == 0) lds_barrier();
         first_stage = false;
-        issue(b_fill);
-        kstep(first_tag, b_cur, 0, b_cur, 1);
-        kstep(std::false_type{}, b_cur, 1, b_nxt, 0);
+        stamp();
+        // (an item's first stage issues its DMA BEHIND the first k-step: hipcc guards the registers the epilogue's stores read with a
+        // vmcnt(0) in front of the first MFMA that overwrites them, which must meet those stores only, not DMA pieces issued a moment ago)
+        // The stage's DMA goes out as one burst per wave at the top of the stage.  (Measured alternatives, DESIGN 2.9: one piece at a time
+        // from inside the MFMA stream, and the two waves of a SIMD bursting in turns -- both slower.)  An item's FIRST stage bursts behind
+        // its first k-step: hipcc guards the registers the epilogue's stores read with a vmcnt(0) in front of the first MFMA that
+        // overwrites them, which must meet those stores only, not DMA pieces issued a moment ago.
+        if constexpr (!FIRST) issue(b_fill);
+        lane_offsets();
+        stamp();
+        if constexpr (FIRST) open_kstep(b_cur);
+        kstep(first_tag, std::true_type{}, b_cur, 0, b_cur, 1);
+        if constexpr (FIRST) issue(b_fill);
+        stamp();
+        if constexpr (LAST) kstep(std::false_type{}, std::false_type{}, b_cur, 1, b_nxt, 0);
+        else kstep(std::false_type{}, std::true_type{}, b_cur, 1, b_nxt, 0);
+        stamp();
         w2d_dma_wait();
+        stamp();
         float* t = b_cur; b_cur = b_nxt; b_nxt = b_fill; b_fill = t;
     };
     for (int k = 0; k < my_items; ++k) {
         const int item = first + slot + k * slots;
         const int tile = item / nmu, mu = item - tile * nmu;
-        stage(std::true_type{});                     // the item's first chunk starts the accumulators (MFMAs on the inline constant 0)
-        for (int c = 1; c < nchunk; ++c) stage(std::false_type{});
+        // the item's first chunk starts the accumulators (MFMAs on the inline constant 0)
+        if (nchunk == 1) stage(std::true_type{}, std::true_type{});
+        else {
+            stage(std::true_type{}, std::false_type{});
+            for (int c = 1; c + 1 < nchunk; ++c) stage(std::false_type{}, std::false_type{});
+            stage(std::false_type{}, std::true_type{});
+        }
+        lane_offsets();
         // ---- epilogue: Y = A^T M A per (row block, register); lane = (tile column l15, channel group ks) holds a 2 x 2 output block
         // per (row block, register).  Lanes l15 and l15 ^ 1 trade halves (one DPP move each way): the even lane stores the upper row
         // of both blocks -- four consecutive columns, one 16-byte store --, the odd lane the lower row: 12 stores per lane and item
         // instead of 24, each wave instruction eight 128-byte runs.
-        if (kAblate && (dbg & 16)) continue;
+        if constexpr ((dbg & 16) != 0) continue;
+        w2d_fence();   // the epilogue's index arithmetic stays out of the last k-step (scheduled into it, it pushed accumulators into scratch memory)
         const int tw_i = tile % p.tiles_w, th_i = (tile / p.tiles_w) % p.tiles_h, n = tile / (p.tiles_w * p.tiles_h);
         const int ho = th_i * NW + 2 * (wave >> 1), wo = tw_i * kW2dCols + 2 * (16 * (wave & 1) + l15);
         const long y_sc = w2d_opaque(p.y_sc), y_sh = w2d_opaque(p.y_sh);
@@ -346,7 +412,7 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
         // the whole wave's 2 x 32 columns exist and rows are 16-byte aligned: the straight-line form
         const bool full = ho + 1 < p.Ho && tw_i * kW2dCols + 32 * (wave & 1) + 32 <= p.Wo && ((p.y_sn | p.y_sc | p.y_sh) & 3) == 0 &&
                           ((uintptr_t)p.y & 15) == 0;
-        auto body = [&](auto act_tag, auto full_tag) {
+        auto body = [&](auto act_tag, auto full_tag) __attribute__((always_inline)) {
             constexpr int ACT = decltype(act_tag)::value;
             constexpr bool FULL = decltype(full_tag)::value;
             const int odd = l15 & 1;
@@ -356,6 +422,7 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
                 const float4 bq = *reinterpret_cast<const float4*>(brow + rb * 16);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
+                    w2d_fence();   // one output channel at a time: hoisted, the twelve store addresses and their temporaries spill accumulators
                     const int m = mu * kW2dM + rb * 16 + 4 * ks + r;
                     const float bm = r == 0 ? bq.x : r == 1 ? bq.y : r == 2 ? bq.z : bq.w;
                     float Wc[4][2];
@@ -375,7 +442,7 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
                         // what the partner needs of this lane: the even lane's lower row, the odd lane's upper row
                         const float g0 = quad_xor1(odd ? y00 : y10), g1 = quad_xor1(odd ? y01 : y11);
                         const float4 v = odd ? make_float4(g0, g1, y10, y11) : make_float4(y00, y01, g0, g1);
-                        if (!(kAblate && (dbg & 128))) *reinterpret_cast<float4*>(dst) = v;
+                        if constexpr ((dbg & 128) == 0) *reinterpret_cast<float4*>(dst) = v;
                         else asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
                     } else {
                         const bool row1 = ho + 1 < p.Ho, col1 = wo + 1 < p.Wo;
@@ -388,6 +455,7 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
                 }
             }
         };
+        stamp();
         if (full) {
             if (p.act == AICG_ACT_NONE) body(std::integral_constant<int, 0>{}, std::true_type{});
             else if (p.act == AICG_ACT_RELU) body(std::integral_constant<int, 1>{}, std::true_type{});
@@ -397,19 +465,21 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
             else if (p.act == AICG_ACT_RELU) body(std::integral_constant<int, 1>{}, std::false_type{});
             else body(std::integral_constant<int, 3>{}, std::false_type{});
         }
+        stamp();
     }
 #ifndef AICG_EMULATED
-    if (kAblate && (dbg & 64) && blockIdx.x == 0 && tid == 0) {
+    if ((dbg & (64 | 256)) != 0 && blockIdx.x == 0 && tid == 0) {
         p.y[0] = (float)(clock64() - clk0);
-        p.y[1] = (float)(wall_clock64() - wall0);
+        p.y[1] = (dbg & 256) ? (float)tr_n : (float)(wall_clock64() - wall0);
     }
 #endif
 }
 
 // returns 0 launched, < 0 error, 1 not applicable.  p.w3 must point at the F(2 x 2, 3 x 3) image of ops.winograd2d_image:
 // [Cout / 48][ceil(Cin / 8)][s = 0..1][point 0..15][ks = 0..3][m = 0..47], element = U[48 mu + m][8 chunk + 4 s + ks][point].
-template <int NW, int PF>
+template <int NW, int PF, int ABL = 0>
 static int launch_conv_w2d(ConvArgs& p, hipStream_t stream) {
+    constexpr int BUFS = 3;
     auto al4 = [](long v) { return (v & 3) == 0; };
     if (p.Cout_g % kW2dM || (p.W & 3) || !al4(p.x_sn) || !al4(p.x_sc) || !al4(p.x_sh) || ((uintptr_t)p.x & 15) || ((uintptr_t)p.w3 & 15)) return 1;
     if ((long)8 * p.x_sc + (long)p.H * p.x_sh >= (1L << 29)) return 1;   // 32-bit byte offsets inside an 8-channel slab
@@ -419,12 +489,13 @@ static int launch_conv_w2d(ConvArgs& p, hipStream_t stream) {
     p.Mpad = p.Cout_g / kW2dM;
     const long nitems = (long)p.N * p.tiles_h * p.tiles_w * p.Mpad;
     if (nitems > 2147483647L - 8) return fail(AICG_E_SHAPE, "conv: too many output tiles");
-    const size_t lds = (size_t)(kW2dBufs * w2d_stage_floats(NW) + p.Cout_g) * sizeof(float);
+    const size_t lds = (size_t)(BUFS * w2d_stage_floats(NW) + ((p.Cout_g + 3) & ~3) + 2 * ((w2d_plane_quads(NW) * 8 / 64 + NW - 1) / NW) * 64 * NW) * sizeof(float);   // stages, bias, DMA decode + offsets
+    if (lds > 160 * 1024) return 1;
     const int per_xcd = (int)((nitems + 7) >> 3);
     int slots = 32;                                   // one workgroup per CU
     if (slots > per_xcd) slots = per_xcd;
-    allow_dynamic_lds((const void*)conv_w2d_kernel<NW, PF>, lds);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_w2d_kernel<NW, PF>), dim3((unsigned)(8 * slots)), dim3(64 * NW), lds, stream, p);
+    allow_dynamic_lds((const void*)conv_w2d_kernel<NW, PF, ABL>, lds);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_w2d_kernel<NW, PF, ABL>), dim3((unsigned)(8 * slots)), dim3(64 * NW), lds, stream, p);
     return check_launch("conv_w2d_kernel");
 }
 
@@ -432,5 +503,6 @@ int run_w2d_8(ConvArgs& p, hipStream_t st);
 int run_w2d_4(ConvArgs& p, hipStream_t st);
 int run_w2d_8q(ConvArgs& p, hipStream_t st);
 int run_w2d_4q(ConvArgs& p, hipStream_t st);
+int run_w2d_ablation(ConvArgs& p, hipStream_t st, int bits);   // dev library only: the 8-wave form with ABL = bits (1 = unknown variant)
 
 }  // namespace aicg

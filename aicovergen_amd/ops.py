@@ -394,6 +394,7 @@ def conv(x, pc, res=None, out=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NON
     # ... its two-dimensional form where the layer has it and the map is float4-aligned
     wino2 = (wino and winograd2d and getattr(pc, "w_wino2", None) is not None and w % 4 == 0 and x4.stride(0) % 4 == 0 and x4.stride(1) % 4 == 0
              and x4.stride(2) % 4 == 0 and x4.data_ptr() % 16 == 0)
+    # 2 / 3: eight / four waves per workgroup; + 2: quad fragments
     d.wino = ((2 if winograd2d_waves == 8 else 3) + (2 if winograd2d_quads else 0)) if wino2 else 1 if wino else 0
     prof = conv_profile
     if prof is not None and x.is_cuda:

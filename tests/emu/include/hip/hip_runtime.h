@@ -205,6 +205,7 @@ inline emu_f32x4 emu_mfma_f32_16x16x4f32(float a, float b, emu_f32x4 c, int, int
 #define __hip_atomic_store(p, v, order, scope) __atomic_store_n(p, v, __ATOMIC_SEQ_CST)
 #define __hip_atomic_fetch_add(p, v, order, scope) __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST)
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_readfirstlane(x) (x)   /* callers pass wave-uniform values */
 #define __builtin_amdgcn_wave_barrier() ::emu::wave_barrier()   /* lanes of a wave run in lockstep on the hardware: rendezvous here */
 #define __builtin_amdgcn_s_barrier() ::emu::block_barrier()
 

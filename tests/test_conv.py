@@ -123,10 +123,10 @@ def test_conv2d_winograd_rows(dev, monkeypatch, n, ci, co, H, W, act):
     assert rel_rms(y, ref + r) < 1e-5
 
 
-@pytest.mark.parametrize("waves", [8, 4])
+@pytest.mark.parametrize("waves,quads", [(8, False), (4, False), (8, True), (4, True)])
 @pytest.mark.parametrize("n,ci,co,H,W,act", [(1, 8, 48, 8, 64, ops.ACT_RELU), (2, 16, 48, 11, 72, ops.ACT_NONE), (1, 24, 96, 5, 132, ops.ACT_RELU),
                                               (1, 12, 48, 17, 60, ops.ACT_RELU), (3, 40, 144, 3, 8, ops.ACT_NONE), (1, 48, 48, 16, 196, ops.ACT_RELU)])
-def test_conv2d_winograd_2d(dev, monkeypatch, waves, n, ci, co, H, W, act):
+def test_conv2d_winograd_2d(dev, monkeypatch, waves, quads, n, ci, co, H, W, act):
     """F(2 x 2, 3 x 3) (csrc/conv_w2d.h) on TFC-shaped layers, in both workgroup forms: one and several M units of 48 channels, input
     channels that are not a multiple of the 8-channel chunk (zeros from the buffer range check / the padded image), odd row counts
     (a row pair whose second row does not exist), ragged and sub-tile widths (multiples of 4), several tiles per workgroup in the
@@ -135,6 +135,7 @@ def test_conv2d_winograd_2d(dev, monkeypatch, waves, n, ci, co, H, W, act):
     monkeypatch.setattr(ops, "winograd_min_positions", 1)
     monkeypatch.setattr(ops, "winograd2d", True)
     monkeypatch.setattr(ops, "winograd2d_waves", waves)
+    monkeypatch.setattr(ops, "winograd2d_quads", quads)      # fragment image [s][p / 4][ks][m][p % 4]: one 16-byte read per four MFMAs
     torch.manual_seed(H * W + ci)
     x = torch.randn(n, ci, H, W)
     w = torch.randn(co, ci, 3, 3) * 0.1

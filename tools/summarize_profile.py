@@ -22,7 +22,7 @@ def find(sub, pat):
 def is_conv(k):
     """the implicit-GEMM convolution family: conv_ws_kernel / conv_ws16_kernel (wave-specialised), conv_mfma_kernel /
     conv_mfma16_kernel (small-problem fallback)"""
-    return k.startswith(("conv_ws_kernel", "conv_ws3_kernel", "conv_ws3s_kernel", "conv_ws3m16_kernel", "conv_ws3m16h_kernel", "conv_ws3w_kernel", "conv_ws16_kernel", "conv_mfma_kernel", "conv_mfma16_kernel", "conv_pointwise_kernel"))
+    return k.startswith(("conv_ws_kernel", "conv_ws3_kernel", "conv_ws3s_kernel", "conv_ws3m16_kernel", "conv_ws3m16h_kernel", "conv_ws3w_kernel", "conv_w2d_kernel", "conv_ws16_kernel", "conv_mfma_kernel", "conv_mfma16_kernel", "conv_pointwise_kernel"))
 
 
 def short(name):
@@ -95,6 +95,42 @@ if cc:
             summary["sq_conv_kernels"]["shader_clock_ghz"] = clk / 1e9
             summary["sq_conv_kernels"]["mfma_pipe_busy_frac"] = conv.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024.0 / t / clk
             summary["sq_conv_kernels"]["wait_inst_any_over_wave_cycles"] = conv.get("SQ_WAIT_INST_ANY", 0) / max(1.0, conv.get("SQ_WAVE_CYCLES", 0))
+
+# ---- per kernel (the six largest by time): HBM traffic per launch against nothing but itself, matrix-pipe occupancy
+if kt and not SPLIT:
+    per = {}
+    top = [k for k, _ in rows[:8]]
+    trace = {k: agg_t for k, agg_t in rows}
+    fetch = defaultdict(lambda: [0, 0.0])
+    write = defaultdict(lambda: [0, 0.0])
+    for sub, counter, dst in (("pmc_fetch", "FETCH_SIZE", fetch), ("pmc_write", "WRITE_SIZE", write)):
+        cc2 = find(sub, "*counter_collection.csv")
+        if cc2:
+            for r in csv.DictReader(open(cc2)):
+                if r.get("Counter_Name") == counter:
+                    a = dst[short(r["Kernel_Name"])]
+                    a[0] += 1
+                    a[1] += float(r["Counter_Value"])
+    sq = defaultdict(lambda: defaultdict(float))
+    cc3 = find("pmc_sq", "*counter_collection.csv")
+    if cc3:
+        for r in csv.DictReader(open(cc3)):
+            sq[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
+    for k in top:
+        c, t = trace[k]
+        row = {"calls": c, "avg_us": t / c, "total_us": t}
+        if fetch[k][0] and write[k][0]:
+            row["hbm_bytes_per_launch_2xfetch_plus_write"] = (2.0 * fetch[k][1] / fetch[k][0] + write[k][1] / write[k][0]) * 1024.0
+            row["hbm_tb_per_s"] = row["hbm_bytes_per_launch_2xfetch_plus_write"] / (t / c * 1e-6) / 1e12
+        d = sq.get(k)
+        if d and d.get("SQ_BUSY_CYCLES"):
+            clk = d["SQ_BUSY_CYCLES"] / 32.0 / (t * 1e-6)
+            row["shader_clock_ghz"] = clk / 1e9
+            row["mfma_pipe_busy_frac"] = d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 1024.0 / (t * 1e-6) / clk
+            row["executed_tflops_f32_mfma"] = d.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0) * 512.0 / (t * 1e-6) / 1e12
+            row["wait_inst_any_over_wave_cycles"] = d.get("SQ_WAIT_INST_ANY", 0.0) / max(1.0, d.get("SQ_WAVE_CYCLES", 0.0))
+        per[k] = row
+    summary["per_kernel_top"] = per
 
 json.dump(summary, open(os.path.join(out_dir, "%s%s_summary.json" % (tag, SUF)), "w"), indent=1)
 print(json.dumps(summary, indent=1)[:6000])
