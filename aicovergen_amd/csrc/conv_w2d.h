@@ -371,7 +371,8 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
         // (an item's first stage issues its DMA BEHIND the first k-step: hipcc guards the registers the epilogue's stores read with a
         // vmcnt(0) in front of the first MFMA that overwrites them, which must meet those stores only, not DMA pieces issued a moment ago)
         // The stage's DMA goes out as one burst per wave at the top of the stage.  (Measured alternatives, DESIGN 2.9: one piece at a time
-        // from inside the MFMA stream, and the two waves of a SIMD bursting in turns -- both slower.)  An item's FIRST stage bursts behind
+        // from inside the MFMA stream -- slower; the two waves of a SIMD bursting in turns -- 6 % slower on level 0, 1 % faster on the
+        // deep levels; the first stage bursting right behind open_kstep -- 1-2 % slower.)  An item's FIRST stage bursts behind
         // its first k-step: hipcc guards the registers the epilogue's stores read with a vmcnt(0) in front of the first MFMA that
         // overwrites them, which must meet those stores only, not DMA pieces issued a moment ago.
         if constexpr (!FIRST) issue(b_fill);

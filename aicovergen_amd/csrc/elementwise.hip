@@ -3,6 +3,8 @@
 // unit-stride along time so every wave issues full 256-byte rows.
 #include "common.h"
 
+#include <cstdint>
+
 namespace aicg {
 
 // ---- col2im: gather form of ConvTranspose (reference models.py:453-463 ups; rmvpe.py:147-155) ---------
@@ -53,7 +55,10 @@ __global__ void __launch_bounds__(256) col2im_kernel(Col2imArgs p) {
 // carried modulo 1 in fp64: frame prefix (one thread block scan) + (i+1)*rad inside the frame.
 __global__ void __launch_bounds__(256) sine_frame_prefix_kernel(const float* __restrict__ f0, double* __restrict__ prefix,
                                                                 int T, int upp, float sr) {
-    // single workgroup: blocked scan over frames; prefix[t] = frac(sum_{u<t} rad_u * upp)
+    // single workgroup: blocked scan over frames; prefix[t] = frac(sum_{u<t} rad_u * upp).  The 256 per-thread partial sums are
+    // combined by thread 0 in index order (the fp64 "add, drop the integer part" chain is order dependent: a tree would round
+    // differently from the sequential reference order the tests pin), from registers of one wave-wide read -- 256 dependent fp64 steps,
+    // ~4 us; the per-thread parts (T / 256 frames each) run in parallel before and after it.
     __shared__ double part[256];
     const int tid = threadIdx.x;
     const int per = (T + 255) / 256;
@@ -82,6 +87,38 @@ __global__ void __launch_bounds__(256) sine_frame_prefix_kernel(const float* __r
         const float rad = fmodf(f0[t] / sr, 1.0f);
         run += (double)rad * (double)upp;
         run -= floor(run);
+    }
+}
+
+// One thread = FOUR consecutive samples of one frame (upp % 4 == 0: 400 / 480 / 320 of the 40k / 48k / 32k models): one float4 of
+// noise in, one float4 out, the frame's f0 / prefix / rad read once.  (r3: one sample per thread, scalar loads and stores, 3 % of the
+// HBM rate; what remains of the time is the two launches and the scan above -- 21 MB per chunk are a 4 us stream.)
+__global__ void __launch_bounds__(256) sine_source4_kernel(const float* __restrict__ f0, const double* __restrict__ prefix,
+                                                           const float* __restrict__ noise, float* __restrict__ out,
+                                                           int T, int upp, float sr, float sine_amp, float noise_std,
+                                                           float lin_w, float lin_b) {
+    const int q_per = upp >> 2;
+    const long total4 = (long)T * q_per;
+    for (long n4 = (long)blockIdx.x * blockDim.x + threadIdx.x; n4 < total4; n4 += (long)gridDim.x * blockDim.x) {
+        const int t = (int)(n4 / q_per);
+        const int i0 = (int)(n4 - (long)t * q_per) * 4;
+        const float f = f0[t];
+        const float rad = fmodf(f / sr, 1.0f);
+        const double base = prefix[t];
+        const float uv = f > 0.f ? 1.f : 0.f;
+        const float namp = uv * noise_std + (1.f - uv) * sine_amp / 3.f;
+        const float4 nz = *reinterpret_cast<const float4*>(noise + (long)t * upp + i0);
+        const float nv[4] = {nz.x, nz.y, nz.z, nz.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double ph = base + (double)(i0 + j + 1) * (double)rad;
+            ph -= floor(ph);
+            const float sine = sinf((float)(ph * 6.283185307179586476925)) * sine_amp;
+            const float v = sine * uv + namp * nv[j];
+            o[j] = tanhf(lin_w * v + lin_b);  // l_linear (1->1) + tanh (models.py:418)
+        }
+        *reinterpret_cast<float4*>(out + (long)t * upp + i0) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 
@@ -190,8 +227,12 @@ extern "C" int aicg_sine_source(const float* f0, const float* noise, double* pre
     if (T < 0 || upp < 1) return fail(AICG_E_SHAPE, "aicg_sine_source: bad shape");
     if (T == 0) return AICG_OK;
     hipLaunchKernelGGL(sine_frame_prefix_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, f0, prefix_scratch, T, upp, sr);
-    hipLaunchKernelGGL(sine_source_kernel, dim3(ew_grid((long)T * upp)), dim3(256), 0, (hipStream_t)stream, f0,
-                       (const double*)prefix_scratch, noise, out, T, upp, sr, sine_amp, noise_std, lin_w, lin_b);
+    if ((upp & 3) == 0 && ((uintptr_t)noise & 15) == 0 && ((uintptr_t)out & 15) == 0)
+        hipLaunchKernelGGL(sine_source4_kernel, dim3(ew_grid((long)T * (upp >> 2))), dim3(256), 0, (hipStream_t)stream, f0,
+                           (const double*)prefix_scratch, noise, out, T, upp, sr, sine_amp, noise_std, lin_w, lin_b);
+    else
+        hipLaunchKernelGGL(sine_source_kernel, dim3(ew_grid((long)T * upp)), dim3(256), 0, (hipStream_t)stream, f0,
+                           (const double*)prefix_scratch, noise, out, T, upp, sr, sine_amp, noise_std, lin_w, lin_b);
     return check_launch("sine_source_kernel");
 }
 

@@ -234,6 +234,7 @@ winograd2d = os.environ.get("AICG_WINOGRAD", "2") == "2"
 winograd2d_waves = int(os.environ.get("AICG_W2D_WAVES", "8"))   # 8: two waves per SIMD on an 8 x 64 tile; 4: one per SIMD on 4 x 64
 
 
+winograd2d_code = int(os.environ.get("AICG_W2D_CODE", "0"))       # tools: a schedule variant under test (aicg_conv_desc.wino 6 ..)
 winograd2d_quads = os.environ.get("AICG_W2D_QUADS", "0") == "1"   # fragment image: [s][p / 4][ks][m][p % 4] (16-byte fragments)
 
 
@@ -395,7 +396,7 @@ def conv(x, pc, res=None, out=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NON
     wino2 = (wino and winograd2d and getattr(pc, "w_wino2", None) is not None and w % 4 == 0 and x4.stride(0) % 4 == 0 and x4.stride(1) % 4 == 0
              and x4.stride(2) % 4 == 0 and x4.data_ptr() % 16 == 0)
     # 2 / 3: eight / four waves per workgroup; + 2: quad fragments
-    d.wino = ((2 if winograd2d_waves == 8 else 3) + (2 if winograd2d_quads else 0)) if wino2 else 1 if wino else 0
+    d.wino = (winograd2d_code or (2 if winograd2d_waves == 8 else 3) + (2 if winograd2d_quads else 0)) if wino2 else 1 if wino else 0
     prof = conv_profile
     if prof is not None and x.is_cuda:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

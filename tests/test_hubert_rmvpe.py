@@ -184,6 +184,54 @@ def test_gru_kernels_match_torch(dev, hidden, T):
         ops.GRU_WORKGROUPS = old
 
 
+@pytest.mark.parametrize("hidden,multi", [(256, True), (256, False), (64, False)])
+def test_gru_in_segments_is_bit_identical(dev, hidden, multi):
+    """The recurrence cut into segments of steps with the hidden state carried (ops.GruSegments -> aicg_gru_bidir_4wg_seg /
+    aicg_gru_bidir_seg) is the SAME arithmetic step by step: bit-identical to one launch, for uneven segment lengths, and the range
+    both directions have passed grows from the middle of the track.  (What the multi-GPU pipeline's progressive f0 rests on)"""
+    torch.manual_seed(hidden + int(multi))
+    T = 75 if not dev.big else 5003
+    gi = dev.t(torch.randn(6 * hidden, T) * 0.5)
+    whh = dev.t(torch.randn(2, hidden, 3 * hidden) * 0.05)
+    bhh = dev.t(torch.randn(6 * hidden) * 0.1)
+    ref = ops.gru_bidir(gi, whh, bhh, hidden, two_workgroups=multi)
+    seg = ops.GruSegments(gi, whh, bhh, hidden, two_workgroups=multi)
+    cuts = [16, 17, T // 2, T - 11, T] if not dev.big else [32, 1000, 1001, T // 2, 4096, T]
+    ranges = []
+    for s1 in cuts:
+        seg.run(s1)
+        ranges.append(seg.ready())
+    dev.sync()
+    assert not ops.gru_timed_out()
+    assert torch.equal(seg.out, ref)
+    assert ranges[0][0] >= ranges[0][1]                       # nothing is final before the directions meet ...
+    assert ranges[-1] == (0, T)                               # ... everything after the last step
+    assert all(a1 <= a0 and b1 >= b0 for (a0, b0), (a1, b1) in zip(ranges, ranges[1:]))
+
+
+def test_rmvpe_progressive_f0_equals_one_launch(dev):
+    """RMVPE.infer_progressive: f0 published range by range as both GRU directions pass the frames, middle of the track first;
+    the union is the one-launch result bit for bit on the emulator (on hardware the classifier GEMM over a frame range may take
+    other tiles than over the whole track: fp32 summation order, 1e-6)."""
+    r = RMVPE(None, False, dev.device, state_dict=weights.small_model_set(1234)["rmvpe_sd"])
+    audio = torch.from_numpy(vocal_like(3.0, 16000, 77))
+    f0 = r.infer_from_audio_device(audio, 0.03).cpu().numpy()
+    got = np.full_like(f0, -1.0)
+    calls = []
+
+    def on_f0(lo, hi, v):
+        got[lo:hi] = v.cpu().numpy()
+        calls.append((lo, hi))
+    n = r.infer_progressive(audio, 0.03, 5, on_f0)
+    dev.sync()
+    assert n == len(f0) and (got >= 0).all()
+    assert calls[0][0] > 0 and calls[0][1] < n                # the first range is in the middle
+    if dev.kind == "emu":
+        assert np.array_equal(got, f0)
+    else:
+        assert np.array_equal(got > 0, f0 > 0) and np.allclose(got, f0, rtol=1e-5)
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.environ.get("AICG_REAL_HUBERT"), reason="set AICG_REAL_HUBERT=<hubert_base.pt> (and install fairseq) to pin HuBERT")
 def test_real_hubert_checkpoint_matches_fairseq():

@@ -34,9 +34,10 @@ for lvl, (c, t, f) in enumerate([(48, 256, 3072), (96, 128, 1536), (144, 64, 768
     td = timeit(lambda: ops.conv(x, pc, act=ops.ACT_RELU, out=out))
     row = [f"L{lvl} c{c} {t}x{f} N{N}: direct {td*1e3:7.3f} ms {fl/td/1e12:6.1f} TF"]
     ops.winograd_min_positions = 1
-    for name, two_d, waves, quads, macs in (("1d", False, 8, False, 1.5), ("2d/8w", True, 8, False, 2.25), ("2d/4w", True, 4, False, 2.25),
-                                            ("2d/8w/q", True, 8, True, 2.25), ("2d/4w/q", True, 4, True, 2.25)):
-        ops.winograd2d, ops.winograd2d_waves, ops.winograd2d_quads = two_d, waves, quads
+    forms = [("1d", False, 8, False, 1.5, 0), ("2d/8w", True, 8, False, 2.25, 0), ("2d/4w", True, 4, False, 2.25, 0),
+             ("2d/8w/q", True, 8, True, 2.25, 0), ("2d/4w/q", True, 4, True, 2.25, 0)]
+    for name, two_d, waves, quads, macs, code in forms:
+        ops.winograd2d, ops.winograd2d_waves, ops.winograd2d_quads, ops.winograd2d_code = two_d, waves, quads, code
         out.zero_()
         tw = timeit(lambda: ops.conv(x, pc, act=ops.ACT_RELU, out=out))
         err = ((out - ref).pow(2).sum() / ref.pow(2).sum()).sqrt().item()

@@ -15,15 +15,15 @@ timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCL
 cd $GRAFT_REPO_ROOT
 python tools/summarize_profile.py $OUT $TAG > $OUT/summary.log 2>&1
 tail -40 $OUT/summary.log
-# opt-in split precision: kernel trace only (profiles/<tag>_split_kernel_stats.csv)
-cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_split -o bench -- $CMD --precision bf16x3 > $OUT/trace_split.log 2>&1
-timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/pmc_sq_split -o bench -- $CMD --precision bf16x3 > $OUT/pmc_sq_split.log 2>&1
-cd $GRAFT_REPO_ROOT
-python tools/summarize_profile.py $OUT $TAG split > $OUT/summary_split.log 2>&1
-cp $(find $OUT/trace_split -name "*kernel_stats.csv" | head -1) $OUT/split_kernel_stats.csv 2>/dev/null
+# the raw kernel_stats of the trace pass rides along; the large per-dispatch CSVs stay on the box
+cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/summary/${TAG}_rocprofv3_kernel_stats_raw.csv 2>/dev/null
+find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete
+# per-form micro-benchmark of the MDX 3x3 layers (direct / F(2,3) rows / F(2x2,3x3))
+python tools/kbench_w2d.py > $OUT/kbench_w2d.txt 2>&1
 # the judged bench lines of this round
-python bench.py > $OUT/bench_c3_default.json 2> $OUT/bench_c3_default.err
+python bench.py --conv-shapes $OUT/conv_shapes_c3.json > $OUT/bench_c3_default.json 2> $OUT/bench_c3_default.err
+AICG_WINOGRAD=1 python bench.py --no-cpu-baseline > $OUT/bench_c3_winograd_rows.json 2>/dev/null
+python bench.py --config C5 --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_c5.json 2>/dev/null
 python bench.py --precision bf16x3 --no-cpu-baseline > $OUT/bench_c3_split.json 2> $OUT/bench_c3_split.err
 python bench.py --config C2 --no-cpu-baseline > $OUT/bench_c2.json 2>/dev/null
 python bench.py --config C4 --no-cpu-baseline > $OUT/bench_c4.json 2>/dev/null
