@@ -65,14 +65,14 @@ def test_round4_lines_report_the_executed_fraction(path):
 
 
 def test_default_line_has_the_cpu_baseline():
-    d = json.loads(open(os.path.join(ROOT, "profiles", "r03_bench_c3_default.json")).read())
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r04_bench_c3_default.json")).read())
     assert d["config"]["config_id"] == "C3" and d["dtype"] == "f32" and "cpu_baseline" in d and d["roofline"]["traffic"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["ref_cpu_seconds"] > 0 and c["ref_threads"] >= 1     # the reference's own C1 time rides along
     assert d["config"]["profiled_step_ms"] > 0 and len(d["config"]["per_rank_seconds_per_step"]) == 1
     # `achieved` counts every layer's direct-form flops; `executed` is what the matrix pipe was given -- the Winograd layers 2/3
     r = d["roofline"]
-    assert 0.6 * r["achieved"] < r["executed"] < r["achieved"] and "Winograd" in r["executed_note"]
+    assert 0.4 * r["achieved"] < r["executed"] < r["achieved"] and "Winograd" in r["executed_note"]   # F(2x2,3x3): 4/9 of those layers' flops
 
 
 def test_stage_table_and_traffic_helpers():
