@@ -42,8 +42,25 @@ static constexpr int V_LD4 = 9;     // float4 per V row in LDS (36 floats: 16-by
 // Key tiles are software-pipelined: the K/V tile kt + 1 is loaded into registers while tile kt is consumed from LDS.
 // Few (query block, head) pairs exist for long single-head-group sequences (enc_p: 52 x 2), so the key range can be split over
 // gridDim.z; each split keeps its own running (max, sum) and attn_combine_kernel merges them (the usual log-sum-exp merge).
-template <int D>
-__global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs p) {
+// r4 (tools/kbench_attn_ab.py, profiles/r04_kbench_attn_ab.txt; HuBERT 12 x 64 at T = 3300 / enc_p 2 x 96 at T = 6600):
+//   OCC   waves per SIMD the register allocation is held to: left alone hipcc took 188 registers at D = 64 and 257 at D = 96 -- two and
+//         ONE wave per SIMD; 158 and 218 cost no spill and admit three and two (0.437 -> 0.418 ms / 0.777 -> 0.673 ms; one more wave
+//         each spills and loses 20 %).
+//   The softmax runs in the base-2 domain: log2 e is folded into the query scale (and the relative-key bias), a score costs one
+//   subtraction and one v_exp_f32 instead of expf's range reduction (-> 0.381 / 0.633 ms), and the running output is rescaled only on
+//   tiles where some lane's maximum moved (alpha is exactly 1 on every lane otherwise; -> 0.625 ms at D = 96).  Error against a float64
+//   softmax unchanged (5.6e-7 / 7.7e-7).  lse and the split-K partial maxima are converted back to the natural domain.
+__device__ __forceinline__ float attn_exp2(float x) {
+#ifdef AICG_EMULATED
+    return exp2f(x);
+#else
+    return __builtin_amdgcn_exp2f(x);   // v_exp_f32: 1 ulp, exp2(-inf) = 0
+#endif
+}
+
+template <int D, int OCC>
+__global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(OCC) attn_fwd_kernel(AttnArgs p) {
+    constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
     constexpr int DT = D / 32;
     constexpr int NL = D * KT / 256;  // K (and V) elements each thread stages per tile
     constexpr int NQ = NL / 4;        // K quads (4 channels of one key) per thread
@@ -61,8 +78,9 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs p) {
 
     // Q^T fragments: qreg[s] = q[2s + half][qi]
     float qreg[D / 2];
+    const float qscale = p.scale * kLog2e;
 #pragma unroll
-    for (int s = 0; s < D / 2; ++s) qreg[s] = (qi < p.T) ? qh[(long)(2 * s + half) * p.ldq + qi] * p.scale : 0.f;
+    for (int s = 0; s < D / 2; ++s) qreg[s] = (qi < p.T) ? qh[(long)(2 * s + half) * p.ldq + qi] * qscale : 0.f;
 
     f32x16 acc[DT];
 #pragma unroll
@@ -135,7 +153,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs p) {
                 const int j = j0 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 const int dlt = j - qi;
                 if (qi < p.T && j < p.T && dlt >= -p.window && dlt <= p.window)
-                    st[r] += rk[(long)(dlt + p.window) * p.T + qi];
+                    st[r] += rk[(long)(dlt + p.window) * p.T + qi] * kLog2e;
             }
         }
         // online softmax over this tile's 32 keys of query qi
@@ -151,20 +169,23 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs p) {
         for (int r = 0; r < 16; ++r) m_t = fmaxf(m_t, st[r]);
         m_t = fmaxf(m_t, __shfl_xor(m_t, 32));
         const float m_new = fmaxf(m_run, m_t);
-        const float alpha = expf(m_run - m_new);
+        const float alpha = attn_exp2(m_run - m_new);
+        const bool moved = __ballot(m_new > m_run) != 0ull;   // (alpha == 1 exactly on every lane otherwise)
         float rs = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            st[r] = expf(st[r] - m_new);
+            st[r] = attn_exp2(st[r] - m_new);
             rs += st[r];
         }
         rs += __shfl_xor(rs, 32);
         l_run = l_run * alpha + rs;
         m_run = m_new;
+        if (moved) {
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+            for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[dt][r] *= alpha;
+                for (int r = 0; r < 16; ++r) acc[dt][r] *= alpha;
+        }
         // O^T += V^T P^T : step r contracts keys (j_r, j_r + 4), j_r = (r & 3) + 8 (r >> 2); the quad q = r >> 2 of a V row is one float4
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -193,7 +214,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs p) {
             }
         if (half == 0) {
             float* pm = p.part + (long)p.nsplit * p.H * D * p.T;
-            pm[sh * p.T + qi] = m_run;
+            pm[sh * p.T + qi] = m_run * kLn2;   // the merge pass works in the natural domain
             pm[((long)p.nsplit * p.H + sh) * p.T + qi] = l_run;
         }
         return;
@@ -207,7 +228,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(AttnArgs p) {
             const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             oh[(long)d * p.ldo + qi] = acc[dt][r] * inv;
         }
-    if (p.lse && half == 0) p.lse[(long)h * p.T + qi] = m_run + logf(l_run);
+    if (p.lse && half == 0) p.lse[(long)h * p.T + qi] = m_run * kLn2 + logf(l_run);
 }
 
 // merge of the split-K partials: o = sum_s acc_s e^{m_s - m} / sum_s l_s e^{m_s - m}; grid (T/256, H, D/16)
@@ -291,10 +312,10 @@ using namespace aicg;
 
 static int attention_launch(AttnArgs& p, int D, hipStream_t stream) {
     dim3 grid((unsigned)idiv_up(p.T, 128), (unsigned)p.H, (unsigned)p.nsplit);
-    if (D == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_fwd_kernel<64>), grid, dim3(256), 0, stream, p);
-    else if (D == 96) hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_fwd_kernel<96>), grid, dim3(256), 0, stream, p);
-    else if (D == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_fwd_kernel<32>), grid, dim3(256), 0, stream, p);
-    else if (D == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_fwd_kernel<128>), grid, dim3(256), 0, stream, p);
+    if (D == 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_fwd_kernel<64, 3>), grid, dim3(256), 0, stream, p);
+    else if (D == 96) hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_fwd_kernel<96, 2>), grid, dim3(256), 0, stream, p);
+    else if (D == 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_fwd_kernel<32, 4>), grid, dim3(256), 0, stream, p);
+    else if (D == 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_fwd_kernel<128, 1>), grid, dim3(256), 0, stream, p);
     else return fail(AICG_E_SHAPE, "aicg_attention: head dim %d not in {32,64,96,128}", D);
     int rc = check_launch("attn_fwd_kernel");
     if (rc != AICG_OK || p.nsplit == 1) return rc;

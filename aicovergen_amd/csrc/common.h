@@ -17,6 +17,13 @@
 #define AICG_SWITCH(var, name, dflt) constexpr long var = (long)(dflt)
 #endif
 
+// waves per SIMD a kernel's register allocation is held to (exactly n: hipcc neither takes more registers nor spills for a higher count)
+#ifdef AICG_EMULATED
+#define AICG_WAVES_PER_SIMD(n)
+#else
+#define AICG_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n, n)))
+#endif
+
 namespace aicg {
 
 // error plumbing: the C ABI returns negative codes and keeps a per-thread message for aicg_last_error()

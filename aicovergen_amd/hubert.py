@@ -180,8 +180,13 @@ class HubertModel:
             offs.append(offs[-1] + t)
         if len(fronts) == 1:
             h = fronts[0]
+            tot = offs[-1]
         else:
-            h = torch.empty((1, E, offs[-1]), dtype=torch.float32, device=fronts[0].device)
+            # the row stride of the side-by-side map is rounded up to 32 tokens: every 128-token tile of the GEMMs then starts on a
+            # cache line (13 198 -> 13 216: 768>3072 94 -> 100, 768>1536 87 -> 95 TFLOP/s, tools/kbench_gemm_probe.py).  The padding
+            # tokens are zeros; every op between here and the final slices acts per token, so they never meet a real one.
+            tot = -(-offs[-1] // 32) * 32
+            h = torch.zeros((1, E, tot), dtype=torch.float32, device=fronts[0].device)
             for f, o in zip(fronts, offs):
                 h[:, :, o:o + f.shape[2]] = f
         del fronts
@@ -193,7 +198,8 @@ class HubertModel:
             if len(lens) == 1:
                 a = ops.attention(q[0], kv[0, :E], kv[0, E:], H)
             else:
-                a = torch.empty((E, offs[-1]), dtype=torch.float32, device=h.device)
+                a = torch.empty((E, tot), dtype=torch.float32, device=h.device)
+                a[:, offs[-1]:] = 0.0
                 for o, t in zip(offs, lens):
                     a[:, o:o + t] = ops.attention(q[0, :, o:o + t], kv[0, :E, o:o + t], kv[0, E:, o:o + t], H)
             a = ops.conv(a.unsqueeze(0), L["o"])

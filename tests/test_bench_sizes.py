@@ -150,7 +150,7 @@ def test_c1_pipeline_with_the_references_f0_injected():
 
 @pytest.mark.parametrize("n", [1056160, 640160])
 def test_chunk_hubert_and_synth_vs_oracle(n):
-    """The chunk sizes of the two presets: (3,10,60,65) -> 1 056 160 samples, T_h = 3300 (4-way split attention, 64x64
+    """The chunk sizes of the two presets: (3,10,60,65) -> 1 056 160 samples, T_h = 3300 (3-way split attention, 64x64
     tiles on the QKV/FFN GEMMs), synthesizer T = 6600 -> 2 640 000 output samples (vocoder tiles of the bench); (1,6,38,41) ->
     640 160 samples, T_h = 2000, T = 4000 -> 1 600 000 samples (other tile / attention-split choices)."""
     from aicovergen_amd.hubert import HubertModel
