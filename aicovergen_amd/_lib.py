@@ -66,6 +66,8 @@ def _load(path, backend):
         fn.restype = ctypes.c_int
     lib.aicg_last_error.restype = ctypes.c_char_p
     lib.aicg_last_error.argtypes = []
+    lib.aicg_last_launch.restype = ctypes.c_char_p
+    lib.aicg_last_launch.argtypes = []
     _lib, _backend = lib, backend
     return lib
 
@@ -92,6 +94,11 @@ def _reset_for_tests():
     global _lib, _backend
     with _lock:
         _lib, _backend = None, None
+
+
+def last_launch():
+    """Name of the kernel family the calling thread's most recent entry point launched (diagnostic; tests assert routing with it)."""
+    return (get().aicg_last_launch() or b"").decode()
 
 
 def call(name, *args):

@@ -27,7 +27,20 @@ def _newer(target, deps):
     if not os.path.exists(target):
         return False
     t = os.path.getmtime(target)
-    return all(os.path.getmtime(d) <= t for d in deps)
+    return all(os.path.exists(d) and os.path.getmtime(d) <= t for d in deps)
+
+
+def _deps(obj, src, hdrs):
+    """What `obj` was compiled from: the compiler's own dependency list (obj.d, written by -MD) restricted to this repository, or --
+    before the first build -- the source plus every header."""
+    dfile = obj + ".d"
+    if not os.path.exists(dfile):
+        return [src] + hdrs
+    text = open(dfile).read().replace("\\\n", " ")
+    names = text.split(":", 1)[1].split() if ":" in text else []
+    root = os.path.realpath(os.path.join(HERE, ".."))
+    mine = [n for n in names if os.path.realpath(n).startswith(root + os.sep)]
+    return mine or [src] + hdrs
 
 
 def build_hip(force=False, verbose=True, dev=False):
@@ -61,8 +74,8 @@ def _build(force, verbose, dev):
     for src in sources():
         obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
         objs.append(obj)
-        if force or not _newer(obj, [src] + hdrs):
-            jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
+        if force or not _newer(obj, _deps(obj, src, hdrs)):
+            jobs.append([hipcc] + flags + ["-MD", "-MF", obj + ".d", "-c", src, "-o", obj])
 
     def run(cmd):
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -44,8 +44,14 @@ int fail(int code, const char* fmt, ...) {
 
 }  // namespace aicg
 
+namespace aicg {
+static thread_local const char* g_last_launch = "";
+void note_launch(const char* what) { g_last_launch = what; }
+}  // namespace aicg
+
 extern "C" const char* aicg_last_error(void) { return aicg::g_err; }
-extern "C" int aicg_abi_version(void) { return 2; }  // 2: aicg_conv_desc gained shuffle / res_mul
+extern "C" const char* aicg_last_launch(void) { return aicg::g_last_launch; }
+extern "C" int aicg_abi_version(void) { return 3; }  // 2: aicg_conv_desc gained shuffle / res_mul; 3: gemm_tile, aicg_last_launch
 
 // Diagnostic: issue-bound fp32 MFMA loop (no memory traffic) to calibrate the attainable v_mfma_f32_32x32x2_f32 rate
 // of the device the benchmarks run on (clock under load is power-dependent).  Returns nothing useful in `out` beyond

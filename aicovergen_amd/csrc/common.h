@@ -30,7 +30,11 @@ namespace aicg {
 void set_error(const char* fmt, ...);
 int fail(int code, const char* fmt, ...);
 
+// name of the kernel family the calling thread launched last (aicg_last_launch(): tests assert WHICH kernel a shape was routed to)
+void note_launch(const char* what);
+
 inline int check_launch(const char* what) {
+    note_launch(what);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(AICG_E_HIP, "%s: %s", what, hipGetErrorString(e));
     return AICG_OK;
@@ -50,9 +54,40 @@ __host__ __device__ inline long lmax(long a, long b) { return a > b ? a : b; }
 // activations shared by conv epilogues and elementwise kernels (codes: include/aicg.h).
 // The transcendental ones are kept out of line: the conv kernels instantiate the activation ~80 times per
 // template variant and inlining erff/tanhf there multiplies the code size past the instruction cache.
+// erf(a) without a branch, < 1 ulp against the exact function over the whole line (checked at 3 million points in
+// tests/test_kernels_misc.py): two minimax fits in the published single-precision form -- |a| <= 0.921875: a + a q(a^2); above:
+// 1 - exp(-(t + t r(t))), t = |a| -- both evaluated (17 FMAs + one v_exp_f32), one select.  The library erff costs ~3x as much and
+// branches per lane; GELU sits in the epilogue of HuBERT's fc1 GEMM and of its feature-extractor convolutions, 40 M evaluations per call.
+__device__ __forceinline__ float fast_erff(float a) {
+    const float t = fabsf(a), s = a * a;
+    float r = fmaf(0x1.222900p-16f, t, -0x1.91d2ccp-12f);
+    const float u = fmaf(0x1.fd1336p-09f, t, -0x1.8d6300p-06f);
+    r = fmaf(r, s, u);
+    r = fmaf(r, t, 0x1.b55cb0p-4f);
+    r = fmaf(r, t, 0x1.450aa0p-1f);
+    r = fmaf(r, t, 0x1.079d0cp-3f);
+    r = fmaf(r, t, t);
+#ifdef AICG_EMULATED
+    r = 1.f - expf(-r);
+#else
+    r = 1.f - __builtin_amdgcn_exp2f(r * -1.44269504088896340736f);   // (r in [0.9, inf): v_exp_f32 needs no range handling here)
+#endif
+    r = copysignf(r, a);
+    float q = -0x1.3a1a82p-11f;
+    q = fmaf(q, s, 0x1.473f48p-08f);
+    q = fmaf(q, s, -0x1.b68bd2p-06f);
+    q = fmaf(q, s, 0x1.ce1a46p-04f);
+    q = fmaf(q, s, -0x1.8126e0p-02f);
+    q = fmaf(q, s, 0x1.06eba6p-03f);
+    q = fmaf(q, a, a);
+    return t > 0.921875f ? r : q;
+}
+// exact-erf GELU (fairseq / HF HuBERT "gelu")
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + fast_erff(v * 0.70710678118654752440f)); }
+
 __device__ __attribute__((noinline)) inline float apply_act_slow(float v, int act, float slope) {
     switch (act) {
-        case AICG_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        case AICG_ACT_GELU: return gelu_erf(v);
         case AICG_ACT_TANH: return tanhf(v);
         case AICG_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
         case AICG_ACT_LOGCLAMP: return logf(fmaxf(v, slope));

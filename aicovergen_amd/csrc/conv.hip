@@ -3,6 +3,7 @@
 #include "conv_ws3s.h"
 #include "conv_ws3w.h"
 #include "conv_w2d.h"
+#include "conv_g1.h"
 
 namespace aicg {
 
@@ -229,6 +230,43 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
             if (few_in) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_pointwise_kernel<true>), grid, dim3(256), 0, (hipStream_t)stream, p);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_pointwise_kernel<false>), grid, dim3(256), 0, (hipStream_t)stream, p);
             return check_launch("conv_pointwise_kernel");
+        }
+    }
+
+    // LDS-DMA staged GEMM (conv_g1.h): 1 x 1 layers over contiguous, 16-byte-aligned maps, no input activation, fp32 path.
+    // aicg_conv_desc.gemm_tile (or, dev builds, AICG_CONV_G1): 0 the policy below, 1 off, 2 / 3 / 4 force the 128 x 256 / 64 x 256 /
+    // 192 x 256 tile (dev: 5 / 6 the 256 x 256 / 128 x 512 probes)
+    {
+        AICG_SWITCH(g1env, "AICG_CONV_G1", 0);
+        const long g1 = d->gemm_tile ? d->gemm_tile : g1env;
+        if (g1 != 1 && !p.wsplit && p.Cout_g > 32 && conv_g1_applicable(p, pad_h_end, pad_w_end)) {
+            const long HW = (long)p.H * p.W;
+            const int M = p.Cout_g;
+            auto wgs = [&](int bm) { return (long)p.N * idiv_up(M, bm) * ldiv_up(HW, 256); };
+            hipStream_t gst = (hipStream_t)stream;
+            int rc = 1;
+            if (g1 == 2) rc = run_g1_128x256(p, gst);
+            else if (g1 == 3) rc = run_g1_64x256(p, gst);
+            else if (g1 == 4) rc = run_g1_192x256(p, gst);
+#ifdef AICG_DEV_SWITCHES
+            else if (g1 == 5) rc = run_g1_256x256(p, gst);
+            else if (g1 == 6) rc = run_g1_128x512(p, gst);
+            else if (g1 >= 12 && g1 <= 14) rc = run_g1_burst(p, gst, (int)g1 - 10);
+#endif
+            else {
+                // Measured (tools/kbench_g1.py, profiles/r04_kbench_g1.txt).  The 192-row tile (one wave per SIMD, 96 x 128 per wave) has the
+                // best rate per tile but needs its launch to come out near a whole number of rounds over the 256 CUs; the 128- / 64-row
+                // tiles (two / three workgroups per CU) hide their barriers and epilogues under each other and tolerate ragged rounds.
+                // HBM-heavy layers (K < 256: the output stream is a large share of the time) take the 64-row tile.  Small problems keep
+                // the small tiles of conv_ws3.
+                const long t192 = wgs(192), t128 = wgs(128), t64 = wgs(64);
+                const bool pad128 = idiv_up(M, 128) * 128 > idiv_up(M, 64) * 64;
+                const double fill192 = (double)t192 / (double)(ldiv_up(t192, 256) * 256);
+                if (M % 192 == 0 && p.Cin_g >= 256 && t192 >= 192 && fill192 >= 0.8) rc = run_g1_192x256(p, gst);
+                else if (!pad128 && p.Cin_g >= 256 && t128 >= 384) rc = run_g1_128x256(p, gst);
+                else if (t64 >= 512) rc = run_g1_64x256(p, gst);
+            }
+            if (rc <= 0) return rc;
         }
     }
 

@@ -110,12 +110,14 @@ __device__ __forceinline__ void trace_val(int, int, unsigned long long) {}
 __device__ __forceinline__ void trace2(int, int, int, int) {}
 #endif
 
-// Epilogue activation with the common cases resolved at compile time (ACT 0 none, 1 ReLU, 2 leaky ReLU, 3 any: run-time code)
+// Epilogue activation with the common cases resolved at compile time (ACT 0 none, 1 ReLU, 2 leaky ReLU, 3 any: run-time code,
+// 4 GELU inline -- conv_g1.h only: ~25 instructions per value where the out-of-line call drains the memory counters per value)
 template <int ACT>
 __device__ __forceinline__ float act_static(float v, int act, float slope) {
     if (ACT == 0) return v;
     if (ACT == 1) return v > 0.f ? v : 0.f;
     if (ACT == 2) return v > 0.f ? v : v * slope;
+    if (ACT == 4) return gelu_erf(v);
     return apply_act(v, act, slope);
 }
 // epi(full_tag, act_tag): one call, chosen by the layer's activation and by whether the tile lies wholly inside the output

@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(256) rownorm_stats_kernel(const float* __restr
 template <int ACT>
 __device__ __forceinline__ float rn_act(float v, int act) {
     if (ACT == AICG_ACT_NONE) return v;
-    if (ACT == AICG_ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    if (ACT == AICG_ACT_GELU) return gelu_erf(v);
     return apply_act(v, act, 0.f);
 }
 

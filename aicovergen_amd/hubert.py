@@ -7,6 +7,7 @@ Linear layers run through the implicit-GEMM conv kernel; attention through the f
 materialised); LayerNorms through layernorm_ct; layer-0 GroupNorm + GELU through rownorm_act.
 """
 import io
+import math
 import pickle
 
 import torch
@@ -98,11 +99,20 @@ class HubertModel:
                                   device=dev)
         P["eln_w"], P["eln_b"] = sd["encoder.layer_norm.weight"].to(dev), sd["encoder.layer_norm.bias"].to(dev)
         layers = []
+        scale = (cfg["embed"] // cfg["heads"]) ** -0.5
         for i in range(cfg["layers"]):
             p = "encoder.layers.%d." % i
-            L = {"q": ops.PackedConv(sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.q_proj.bias"], device=dev),
-                 "kv": ops.PackedConv(torch.cat([sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.v_proj.weight"]], 0),
-                                      torch.cat([sd[p + "self_attn.k_proj.bias"], sd[p + "self_attn.v_proj.bias"]], 0), device=dev),
+            qw, qb = sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.q_proj.bias"]
+            kvw = torch.cat([sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.v_proj.weight"]], 0)
+            kvb = torch.cat([sd[p + "self_attn.k_proj.bias"], sd[p + "self_attn.v_proj.bias"]], 0)
+            if math.frexp(scale)[0] == 0.5:
+                # head_dim ** -0.5 is a power of two (HuBERT-base: 64 -> 1/8): scaling q's rows of the weights and its bias instead of the
+                # GEMM's result is EXACT in fp32, and q, k, v become one 3 E-row GEMM (2 304 rows: 18 x 52 tiles instead of 6 x 52 + 12 x 52
+                # in two launches -- 432 vs 515 us at the benched 13 216 tokens, profiles/r04_kbench_g1.txt)
+                proj = {"qkv": ops.PackedConv(torch.cat([qw * scale, kvw], 0), torch.cat([qb * scale, kvb], 0), device=dev)}
+            else:
+                proj = {"q": ops.PackedConv(qw, qb, device=dev), "kv": ops.PackedConv(kvw, kvb, device=dev)}
+            L = {**proj,
                  "o": ops.PackedConv(sd[p + "self_attn.out_proj.weight"], sd[p + "self_attn.out_proj.bias"], device=dev),
                  "fc1": ops.PackedConv(sd[p + "fc1.weight"], sd[p + "fc1.bias"], device=dev),
                  "fc2": ops.PackedConv(sd[p + "fc2.weight"], sd[p + "fc2.bias"], device=dev),
@@ -193,8 +203,12 @@ class HubertModel:
         h = ops.layernorm_ct(h, P["eln_w"], P["eln_b"])
         n_layers = cfg["layers"] if output_layer is None else min(output_layer, cfg["layers"])
         for L in P["layers"][:n_layers]:
-            q = ops.conv(h, L["q"], out_scale=(E // H) ** -0.5)
-            kv = ops.conv(h, L["kv"])
+            if "qkv" in L:
+                qkv = ops.conv(h, L["qkv"])
+                q, kv = qkv[:, :E], qkv[:, E:]
+            else:
+                q = ops.conv(h, L["q"], out_scale=(E // H) ** -0.5)
+                kv = ops.conv(h, L["kv"])
             if len(lens) == 1:
                 a = ops.attention(q[0], kv[0, :E], kv[0, E:], H)
             else:

@@ -146,7 +146,7 @@ class ConvDesc(ctypes.Structure):
                 ("act_slope", ctypes.c_float), ("out_scale", ctypes.c_float), ("accumulate", ctypes.c_int32),
                 ("res_before_act", ctypes.c_int32), ("pad_h_end", ctypes.c_int32), ("pad_w_end", ctypes.c_int32),
                 ("shuffle", ctypes.c_int32), ("res_mul", ctypes.c_int32), ("packed_v3", ctypes.c_int32),
-                ("split", ctypes.c_int32), ("wino", ctypes.c_int32)]
+                ("split", ctypes.c_int32), ("wino", ctypes.c_int32), ("gemm_tile", ctypes.c_int32)]
 
 
 def conv_bkc(taps):
@@ -337,6 +337,9 @@ class ConvProfile:
 
 conv_profile = None
 
+# tools: aicg_conv_desc.gemm_tile of every launch (0 = the library's policy; 1 keeps 1 x 1 layers off csrc/conv_g1.h; 2 / 3 / 4 force a tile)
+gemm_tile = 0
+
 
 def conv(x, pc, res=None, out=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NONE, act_slope=0.0, out_scale=1.0,
          accumulate=False, bias=None, res_before_act=False, out_len=None, shuffle=0, res_mul=False):
@@ -396,6 +399,7 @@ def conv(x, pc, res=None, out=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NON
     wino2 = (wino and winograd2d and getattr(pc, "w_wino2", None) is not None and w % 4 == 0 and x4.stride(0) % 4 == 0 and x4.stride(1) % 4 == 0
              and x4.stride(2) % 4 == 0 and x4.data_ptr() % 16 == 0)
     # 2 / 3: eight / four waves per workgroup; + 2: quad fragments
+    d.gemm_tile = gemm_tile
     d.wino = (winograd2d_code or (2 if winograd2d_waves == 8 else 3) + (2 if winograd2d_quads else 0)) if wino2 else 1 if wino else 0
     prof = conv_profile
     if prof is not None and x.is_cuda:

@@ -37,6 +37,8 @@ extern "C" {
 #define AICG_ACT_LOGCLAMP 6 /* log(max(v, slope)): log-mel of rmvpe.MelSpectrogram (src/rmvpe.py:324) */
 
 const char* aicg_last_error(void);
+/* Diagnostic: name of the kernel family the calling thread's most recent entry point launched ("" before the first launch) */
+const char* aicg_last_launch(void);
 /* ABI version; bumped whenever a signature changes */
 int aicg_abi_version(void);
 /* Diagnostic: pure v_mfma_f32_32x32x2_f32 issue loop (n_blocks x 256 threads, 4*iters MFMAs per wave) to calibrate the
@@ -129,6 +131,10 @@ typedef struct aicg_conv_desc {
                                      [Cout / 48][ceil(Cin / 8)][s = 0..1][point p = 4 i + q][ks = 0..3][m = 0..47] floats with element
                                      U[48 mu + m][8 chunk + 4 s + ks][i][q], U = G g G^T, G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]
                                      (zero beyond Cin).  Needs Cout % 48 == 0, W % 4 == 0, x 16-byte aligned with strides % 4 == 0 */
+    int32_t gemm_tile;            /* 1 x 1 layers the LDS-DMA staged GEMM can take (csrc/conv_g1.h: unit stride, no padding, one group, no
+                                     input activation, contiguous 16-byte-aligned maps of a multiple of 4 positions): 0 the library's
+                                     policy; 1 never that kernel; 2 / 3 / 4 its 128 x 256 / 64 x 256 / 192 x 256 tile (rows x positions
+                                     per workgroup).  Layers the kernel cannot take ignore the field */
 } aicg_conv_desc;
 
 int aicg_conv_bkc(int taps);

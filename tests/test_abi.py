@@ -30,8 +30,8 @@ def test_header_prototypes_parse():
     names = _declared()
     assert len(names) >= 35
     # every function-like name in the header is an `int aicg_*(...)` prototype the ctypes loader understands,
-    # except the one `const char*` accessor
-    assert set(names) - set(protos) <= {"aicg_last_error"}
+    # except the two `const char*` accessors
+    assert set(names) - set(protos) <= {"aicg_last_error", "aicg_last_launch"}
 
 
 def test_hip_library_exports_every_declared_symbol(hip_lib):
@@ -41,7 +41,7 @@ def test_hip_library_exports_every_declared_symbol(hip_lib):
 
 def test_abi_version_and_error_reporting_without_gpu(hip_lib):
     hip_lib.aicg_abi_version.restype = ctypes.c_int
-    assert hip_lib.aicg_abi_version() == 2
+    assert hip_lib.aicg_abi_version() == 3
     hip_lib.aicg_last_error.restype = ctypes.c_char_p
     # argument validation happens before any HIP call: null pointers -> AICG_E_ARG (-2) and a message, no device needed
     hip_lib.aicg_complex_abs.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_void_p]

@@ -200,3 +200,16 @@ def test_linear_last_nt_gemm(dev, R, K, O):
     _lib.call("aicg_gemm_nt", xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), scd.data_ptr(), shd.data_ptr(), rd.data_ptr(),
               o.data_ptr(), R, K, O, K, K, O, O, rows_per_ch, n_ch, ops.ACT_RELU, st)
     assert rel_rms(o, ref) < 1e-5
+
+
+def test_gelu_erf_over_the_whole_line(dev):
+    """The branch-free erf behind every GELU epilogue (csrc/common.h fast_erff; fairseq's exact-erf "gelu", reference
+    src/rvc.py:98-109 loads the model that uses it) against float64: 0.5 v (1 + erf(v / sqrt 2)) within 4e-7 x max(1, |result|) over [-9, 9] on a
+    dense grid plus normal samples -- fp32 rounding of the product, i.e. erf itself within ~1 ulp."""
+    torch.manual_seed(0)
+    n = 3_000_000 if dev.big else 300_000
+    v = torch.cat([torch.linspace(-9.0, 9.0, n), torch.randn(n) * 2.0]).view(1, 1, -1)
+    y = ops.channel_affine(dev.t(v), dev.t(torch.ones(1)), dev.t(torch.zeros(1)), act=ops.ACT_GELU).cpu().double()
+    ref = 0.5 * v.double() * (1.0 + torch.erf(v.double() / 2.0 ** 0.5))
+    err = (y - ref).abs()
+    assert float((err / ref.abs().clamp_min(1.0)).max()) < 4e-7, float((err / ref.abs().clamp_min(1.0)).max())   # (half an ulp of the result above 1)
