@@ -254,17 +254,21 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
             else if (g1 >= 12 && g1 <= 14) rc = run_g1_burst(p, gst, (int)g1 - 10);
 #endif
             else {
-                // Measured (tools/kbench_g1.py, profiles/r04_kbench_g1.txt).  The 192-row tile (one wave per SIMD, 96 x 128 per wave) has the
-                // best rate per tile but needs its launch to come out near a whole number of rounds over the 256 CUs; the 128- / 64-row
-                // tiles (two / three workgroups per CU) hide their barriers and epilogues under each other and tolerate ragged rounds.
-                // HBM-heavy layers (K < 256: the output stream is a large share of the time) take the 64-row tile.  Small problems keep
-                // the small tiles of conv_ws3.
-                const long t192 = wgs(192), t128 = wgs(128), t64 = wgs(64);
-                const bool pad128 = idiv_up(M, 128) * 128 > idiv_up(M, 64) * 64;
-                const double fill192 = (double)t192 / (double)(ldiv_up(t192, 256) * 256);
-                if (M % 192 == 0 && p.Cin_g >= 256 && t192 >= 192 && fill192 >= 0.8) rc = run_g1_192x256(p, gst);
-                else if (!pad128 && p.Cin_g >= 256 && t128 >= 384) rc = run_g1_128x256(p, gst);
-                else if (t64 >= 512) rc = run_g1_64x256(p, gst);
+                // Measured (tools/kbench_g1.py, profiles/r04_kbench_g1.txt: 24 shapes x 3 tiles, round-robin): every tile runs at ~0.8 of
+                // the MFMA time of the rows it covers, and a launch takes as long as its busiest CU -- ceil(tiles / 256) tiles of BM rows,
+                // whether they share the CU's SIMDs (two / three workgroups per CU) or follow each other.  So: the tile with the least
+                // ceil(tiles / 256) x BM, padded rows included; the 64-row tile pays ~4 % for its DMA traffic, the 192-row one gains ~2 %
+                // but runs one workgroup per CU with its epilogue exposed -- not for short K (the output stream dominates there).
+                // Fewer than 256 workgroups of 64 rows: the small tiles of conv_ws3 fill the chip better.
+                const long t64 = wgs(64);
+                if (t64 >= 256) {
+                    auto cost = [&](int bm, double f) { return (double)ldiv_up(wgs(bm), 256) * bm * f; };
+                    const double c64 = cost(64, 1.04), c128 = cost(128, 1.0);
+                    const double c192 = (M % 192 == 0 && p.Cin_g >= 256) ? cost(192, 0.98) : 1e30;
+                    if (c192 <= c64 && c192 <= c128) rc = run_g1_192x256(p, gst);
+                    else if (c128 <= c64) rc = run_g1_128x256(p, gst);
+                    else rc = run_g1_64x256(p, gst);
+                }
             }
             if (rc <= 0) return rc;
         }

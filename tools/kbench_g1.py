@@ -11,7 +11,7 @@ from aicovergen_amd import _lib, ops  # noqa: E402
 _lib._use_library_for_tests(os.path.join(ROOT, "aicovergen_amd", "libaicg_hip_dev.so"), "hip")
 dev = torch.device("cuda:0")
 NAMES = {1: "ws3", 0: "policy", 2: "128x256", 3: "64x256", 4: "192x256", 5: "256x256", 6: "128x512", 12: "128b", 13: "64b", 14: "192b"}
-codes = [int(c) for c in (sys.argv[1].split(",") if len(sys.argv) > 1 else "1,0,2,3,4,12,13,14")]
+codes = [int(c) for c in (sys.argv[1] if len(sys.argv) > 1 else "1,0,2,3,4,12,13,14").split(",")]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 
 
