@@ -233,7 +233,7 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
         }
     }
 
-    // LDS-DMA staged GEMM (conv_g1.h): 1 x 1 layers over contiguous, 16-byte-aligned maps, no input activation, fp32 path.
+    // LDS-DMA staged GEMM (conv_g1.h): 1 x 1 layers over contiguous, 16-byte-aligned maps, no input activation but a leaky ReLU, fp32 path.
     // aicg_conv_desc.gemm_tile (or, dev builds, AICG_CONV_G1): 0 the policy below, 1 off, 2 / 3 / 4 force the 128 x 256 / 64 x 256 /
     // 192 x 256 tile (dev: 5 / 6 the 256 x 256 / 128 x 512 probes)
     {

@@ -20,7 +20,7 @@
 // (two k-groups of 8 = four MFMA k-steps each), THREE LDS buffers; a wave waits for its own DMA pieces, the LDS-only barrier
 // publishes them (the pipeline is described at the loop).
 // Zero padding -- channels past Cin, positions past the end of the map, rows past Mpad -- is the buffer range check's (offset
-// kBufOob, or past num_records).  pre_act layers (the operand would need a pass through registers) stay on conv_ws3.
+// kBufOob, or past num_records).  Input activations other than a leaky ReLU stay on conv_ws3.
 #pragma once
 #include "conv_w2d.h"
 
@@ -41,7 +41,9 @@ __device__ __forceinline__ void g1_wait_pieces() {   // at most N of this wave's
 // SHUF: the kernel = stride = 2 ConvTranspose2d scatter (ConvArgs::shuffle == 2) with its additive / multiplicative skip operand.
 // WPS: waves per SIMD the register allocation is held to.
 // SPREAD: the DMA pieces of a stage go out one at a time between the MFMAs (see mma_group) instead of as one burst behind the barrier.
-template <int TM, int WM, int WN, bool SHUF, int WPS, bool SPREAD>
+// PRE: a leaky-ReLU input activation (0 <= slope <= 1: the vocoder's up-sampling GEMMs, models.py:503), applied to the B fragments in
+// registers right in front of the k-step that consumes them -- 8 VALU operations under the previous k-step's 4 TM MFMAs.
+template <int TM, int WM, int WN, bool SHUF, int WPS, bool SPREAD, bool PRE>
 __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1_kernel(ConvArgs p) {
     static_assert(WM * WN == 4, "four waves");
     constexpr int BM = 32 * TM * WM, BN = 128 * WN;
@@ -123,6 +125,7 @@ __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1_kernel(C
     // `dma`: this group also carries the wave's DMA pieces of the stage two ahead, ONE PIECE BETWEEN TWO BLOCKS OF FOUR MFMAs -- a piece
     // costs the wave ~60-180 cycles of issue (M0 juggling + the buffer instruction); in one burst behind the barrier that was 10-15 %
     // of a stage with the matrix pipe idle, spread out it disappears under the 256 cycles of the block in front of it
+    const float pre_slope = p.pre_slope;
     auto mma_group = [&](const float4 (&a)[TM], const float4 (&b)[4], auto dma_tag, bool more, float* fill) __attribute__((always_inline)) {
         constexpr bool DMA = decltype(dma_tag)::value;
         constexpr int NBLK = 4 * TM;
@@ -131,10 +134,15 @@ __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1_kernel(C
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const float av = s == 0 ? a[i].x : s == 1 ? a[i].y : s == 2 ? a[i].z : a[i].w;
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[s].x, acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[s].y, acc[i][1], 0, 0, 0);
-                acc[i][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[s].z, acc[i][2], 0, 0, 0);
-                acc[i][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[s].w, acc[i][3], 0, 0, 0);
+                float4 bv = b[s];
+                if constexpr (PRE) {   // lrelu(v) = max(v, slope v) for 0 <= slope <= 1 (same bits for every finite v)
+                    bv.x = fmaxf(bv.x, bv.x * pre_slope); bv.y = fmaxf(bv.y, bv.y * pre_slope);
+                    bv.z = fmaxf(bv.z, bv.z * pre_slope); bv.w = fmaxf(bv.w, bv.w * pre_slope);
+                }
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.x, acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.y, acc[i][1], 0, 0, 0);
+                acc[i][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.z, acc[i][2], 0, 0, 0);
+                acc[i][3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.w, acc[i][3], 0, 0, 0);
                 if constexpr (DMA) {
                     const int blk = s * TM + i;
                     w2d_fence();
@@ -266,13 +274,14 @@ __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1_kernel(C
     else body(std::integral_constant<int, 3>{});
 }
 
-// host side: does the layer have the form this kernel takes?  (1 x 1, unit stride, no padding, one group, no input activation,
-// contiguous 16-byte-aligned maps whose size is a multiple of 4)
+// host side: does the layer have the form this kernel takes?  (1 x 1, unit stride, no padding, one group, no input activation
+// but a leaky ReLU, contiguous 16-byte-aligned maps whose size is a multiple of 4)
 inline bool conv_g1_applicable(const ConvArgs& p, int pad_h_end, int pad_w_end) {
     auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     auto m4 = [](long v) { return (v & 3) == 0; };
     if (p.taps != 1 || p.groups != 1 || p.sh != 1 || p.sw != 1 || p.ph || p.pw || pad_h_end || pad_w_end || !p.w3) return false;
-    if (p.pre_act != AICG_ACT_NONE || p.Ho != p.H || p.Wo != p.W || p.Cin_g < 8) return false;
+    if (p.pre_act != AICG_ACT_NONE && !(p.pre_act == AICG_ACT_LRELU && p.pre_slope >= 0.f && p.pre_slope <= 1.f && !p.shuffle)) return false;
+    if (p.Ho != p.H || p.Wo != p.W || p.Cin_g < 8) return false;
     const long HW = (long)p.H * p.W;
     if ((HW & 3) || HW >= (1L << 24) || p.x_sc >= (1L << 24) || (p.Cin_g > 1 && p.x_sc < HW)) return false;   // 32-bit byte offsets of a 16-row stage
     if (p.H > 1 && p.x_sh != p.W) return false;                                // a channel's positions are one contiguous run
@@ -297,7 +306,8 @@ static int launch_conv_g1(ConvArgs& p, hipStream_t stream) {
     if (nwg > 2147483647L) return fail(AICG_E_SHAPE, "conv: too many output tiles");
     const size_t lds = (size_t)kG1Bufs * g1_stage_floats(BM, BN) * sizeof(float);
     if (lds > 160 * 1024) return 1;
-    auto kern = p.shuffle ? conv_g1_kernel<TM, WM, WN, true, WPS, SPREAD> : conv_g1_kernel<TM, WM, WN, false, WPS, SPREAD>;
+    auto kern = p.shuffle ? conv_g1_kernel<TM, WM, WN, true, WPS, SPREAD, false>
+                          : p.pre_act != AICG_ACT_NONE ? conv_g1_kernel<TM, WM, WN, false, WPS, SPREAD, true> : conv_g1_kernel<TM, WM, WN, false, WPS, SPREAD, false>;
     allow_dynamic_lds((const void*)kern, lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, stream, p);
     return check_launch("conv_g1_kernel");

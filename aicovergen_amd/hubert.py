@@ -105,7 +105,7 @@ class HubertModel:
             qw, qb = sd[p + "self_attn.q_proj.weight"], sd[p + "self_attn.q_proj.bias"]
             kvw = torch.cat([sd[p + "self_attn.k_proj.weight"], sd[p + "self_attn.v_proj.weight"]], 0)
             kvb = torch.cat([sd[p + "self_attn.k_proj.bias"], sd[p + "self_attn.v_proj.bias"]], 0)
-            if math.frexp(scale)[0] == 0.5:
+            if self.merge_qkv and math.frexp(scale)[0] == 0.5:
                 # head_dim ** -0.5 is a power of two (HuBERT-base: 64 -> 1/8): scaling q's rows of the weights and its bias instead of the
                 # GEMM's result is EXACT in fp32, and q, k, v become one 3 E-row GEMM (2 304 rows: 18 x 52 tiles instead of 6 x 52 + 12 x 52
                 # in two launches -- 432 vs 515 us at the benched 13 216 tokens, profiles/r04_kbench_g1.txt)
@@ -131,6 +131,7 @@ class HubertModel:
         assert source.dim() == 2 and source.shape[0] == 1, "one chunk at a time, as VC.vc calls it"
         return self.extract_features_many([source], output_layer)[0], padding_mask
 
+    merge_qkv = True              # q, k, v as one GEMM where folding head_dim ** -0.5 into q's weights is exact (tests switch it off)
     max_tokens_per_pass = 32768   # extract_features_many: tokens laid side by side per transformer pass (~0.4 GB of fc1 output)
 
     def _frontend(self, source):

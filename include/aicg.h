@@ -132,7 +132,7 @@ typedef struct aicg_conv_desc {
                                      U[48 mu + m][8 chunk + 4 s + ks][i][q], U = G g G^T, G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]
                                      (zero beyond Cin).  Needs Cout % 48 == 0, W % 4 == 0, x 16-byte aligned with strides % 4 == 0 */
     int32_t gemm_tile;            /* 1 x 1 layers the LDS-DMA staged GEMM can take (csrc/conv_g1.h: unit stride, no padding, one group, no
-                                     input activation, contiguous 16-byte-aligned maps of a multiple of 4 positions): 0 the library's
+                                     input activation but a leaky ReLU, contiguous 16-byte-aligned maps of a multiple of 4 positions): 0 the library's
                                      policy; 1 never that kernel; 2 / 3 / 4 its 128 x 256 / 64 x 256 / 192 x 256 tile (rows x positions
                                      per workgroup).  Layers the kernel cannot take ignore the field */
 } aicg_conv_desc;

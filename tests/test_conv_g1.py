@@ -27,6 +27,8 @@ for (n, ci, co, h, w) in cases:
     assert rel(ops.conv(x, pc, act=ops.ACT_GELU, out_scale=0.5), 0.5 * gelu(ref)) < 1e-5, ("gelu", n, ci, co, h, w)
     assert rel(ops.conv(x, pc, res=r, act=ops.ACT_RELU), F.relu(ref) + r) < 1e-5, ("res", n, ci, co, h, w)
     assert rel(ops.conv(x, pc, res=r, act=ops.ACT_LRELU, act_slope=0.1, res_before_act=True), F.leaky_relu(ref + r, 0.1)) < 1e-5, ("res first", n, ci, co, h, w)
+    assert rel(ops.conv(x, pc, pre_act=ops.ACT_LRELU, pre_slope=0.1, res=r), F.conv2d(F.leaky_relu(x, 0.1), wt, b) + r) < 1e-5, ("lrelu in", n, ci, co, h, w)
+    assert _lib.last_launch() == "conv_g1_kernel", _lib.last_launch()
     y = y0.clone()
     ops.conv(x, pc, out=y, accumulate=True, out_scale=1 / 3)
     assert rel(y, y0 + ref / 3) < 1e-5, ("accumulate", n, ci, co, h, w)

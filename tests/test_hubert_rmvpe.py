@@ -55,6 +55,37 @@ def test_hubert_many_chunks_at_once(dev):
         assert rel_rms(nine[1], ohub.extract_features(sd, cfg, wavs[1], 9)) < 1e-4
 
 
+def test_hubert_qkv_as_one_gemm_is_exact(dev):
+    """head_dim = 64 (HuBERT-base's): head_dim ** -0.5 = 1/8 is a power of two, q / k / v run as ONE 3 E-row GEMM with the scale folded
+    into q's rows of the weights and bias.  Scaling by a power of two commutes with every fp32 rounding: the merged GEMM's q rows equal
+    the separate GEMM's (scaled in its epilogue) BIT FOR BIT when both run the same kernel family (same accumulation order: asserted on
+    a map large enough for conv_ws3 / conv_g1 either way); end to end the two model forms agree to summation-order noise and both match
+    the oracle."""
+    from aicovergen_amd import _lib
+    torch.manual_seed(3)
+    E, T = 64, 6000 if dev.big else 700
+    h = dev.t(torch.randn(1, E, T))
+    qw, qb, kvw, kvb = torch.randn(E, E) * 0.1, torch.randn(E), torch.randn(2 * E, E) * 0.1, torch.randn(2 * E)
+    q = ops.conv(h, ops.PackedConv(qw, qb, device=dev.device), out_scale=0.125)
+    k1 = _lib.last_launch()
+    qkv = ops.conv(h, ops.PackedConv(torch.cat([qw * 0.125, kvw], 0), torch.cat([qb * 0.125, kvb], 0), device=dev.device))
+    if _lib.last_launch() == k1:
+        assert torch.equal(q, qkv[:, :E])
+    assert rel_rms(q, qkv[:, :E]) < 1e-6
+    cfg = dict(weights.HUBERT_TINY, heads=1)
+    sd = weights.hubert_state_dict(cfg, 77)
+    wav = dev.t(torch.randn(1, 6000) * 0.3)
+    one = HubertModel(sd, cfg).to(dev.device)
+    two = HubertModel(sd, cfg).to(dev.device)
+    two.merge_qkv = False
+    assert "qkv" in one._prepare()["layers"][0] and "q" in two._prepare()["layers"][0]
+    ya, _ = one.extract_features(source=wav, padding_mask=None, output_layer=12)
+    yb, _ = two.extract_features(source=wav, padding_mask=None, output_layer=12)
+    assert rel_rms(ya, yb) < 2e-6
+    with torch.no_grad():
+        assert rel_rms(ya, ohub.extract_features(sd, cfg, wav.cpu(), 12)) < 1e-4
+
+
 def test_hubert_cfg_inferred_from_shapes():
     sd = weights.hubert_state_dict(weights.HUBERT_TINY, 1)
     cfg = _infer_cfg(sd)
