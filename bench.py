@@ -403,7 +403,7 @@ def main():
                 "executed_note": "TFLOP/s the matrix pipe was given: the 3x3 TFC layers of MDX-Net run the Winograd F(2x2,3x3) kernel "
                                  "(conv_w2d: 16 instead of 36 multiply-adds per 2x2 output block; AICG_WINOGRAD=1: the F(2,3)-along-rows "
                                  "kernel conv_ws3w, 2/3); `achieved` counts every layer's direct-form flops, `frac` = executed / peak",
-                "kernel": "conv family (fp32 MFMA: conv_ws3 / conv_ws3m16h implicit GEMM, conv_w2d Winograd F(2x2,3x3))" if not split_mode
+                "kernel": "conv family (fp32 MFMA: conv_ws3 / conv_ws3m16h implicit GEMM, conv_g1 LDS-DMA staged 1x1 GEMM, conv_w2d Winograd F(2x2,3x3))" if not split_mode
                 else "conv family (split precision: conv_ws3s on the bf16 MFMA, 3 MFMAs per product -- achieved and peak are "
                      "in fp32-equivalent TFLOP/s, peak = 2516.6 / 3; the f0 models' layers run the fp32 kernels)",
                 "measured": "HIP events around every launch of one extra step of the same work, taken right behind the timed "
