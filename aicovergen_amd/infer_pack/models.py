@@ -7,7 +7,9 @@ torch recomputes every forward in the reference) and sequences kernel launches; 
 forward pass is a kernel of libaicg_hip.so (aicovergen_amd/ops.py).  Activations are fp32 channel-major
 (1, C, T), the same layout the reference uses.
 """
+import contextlib
 import math
+import os
 from collections import namedtuple
 
 import numpy as np
@@ -275,29 +277,63 @@ class _SynthesizerBase:
                     add = ops.conv(har.view(1, 1, L), nc)
             x = ops.conv_transpose(x, pt, add=add, pre_act=ops.ACT_LRELU, pre_slope=LRELU_SLOPE)
             acc = torch.empty_like(x)
-            tmp = torch.empty_like(x)
-            ya, yb = torch.empty_like(x), torch.empty_like(x)
+            # The num_kernels ResBlocks of a stage read the same x and are independent up to their last convolution, which adds into
+            # the shared sum (models.py:506-512).  On the GPU each chain runs on its own stream: a launch here is 2-24 rounds of
+            # workgroups over the chip, and its ragged last round (the 256-channel stage: 1 142 tiles on 512 slots = 2.2 rounds) runs
+            # under another chain's launch instead of leaving CUs idle.  The accumulating convolutions stay ordered k = 3, 7, 11 by
+            # events, so the sum is formed in the reference's order: output bit-identical to the one-stream walk (AICG_RB_STREAMS=0).
+            streams = self._rb_streams(x.device, nk)
+            main = torch.cuda.current_stream(x.device) if streams else None
+            bufs = [tuple(torch.empty_like(x) for _ in range(3)) for _ in range(nk if streams else 1)]
+            if streams:
+                ready = torch.cuda.Event()
+                ready.record(main)
+            prev_acc = None
             for j in range(nk):
                 convs = P["resblocks"][i * nk + j]
-                y = x
-                for m, (c1, c2) in enumerate(convs):
-                    last = m == len(convs) - 1
-                    if c2 is None:  # ResBlock2
-                        src = c1
-                        inp = y
-                    else:
-                        ops.conv(y, c1, out=tmp, pre_act=ops.ACT_LRELU, pre_slope=LRELU_SLOPE)
-                        src, inp = c2, tmp
-                    if last:  # xs += resblock(x); x = xs / num_kernels  (models.py:506-512)
-                        ops.conv(inp, src, res=y, out=acc, pre_act=ops.ACT_LRELU, pre_slope=LRELU_SLOPE, out_scale=1.0 / nk,
-                                 accumulate=j > 0)
-                    else:
-                        dst = ya if y is not ya else yb
-                        ops.conv(inp, src, res=y, out=dst, pre_act=ops.ACT_LRELU, pre_slope=LRELU_SLOPE)
-                        y = dst
+                st = streams[j - 1] if (streams and j > 0) else main
+                if streams and j > 0:
+                    st.wait_event(ready)
+                with (torch.cuda.stream(st) if streams else contextlib.nullcontext()):
+                    # (buffers of a chain come from the main stream's pool -- allocated before the stream switch -- and stay referenced
+                    #  until the main stream has waited for the last chain: no cross-stream reuse while a side stream still reads them)
+                    tmp, ya, yb = bufs[j] if streams else bufs[0]
+                    y = x
+                    for m, (c1, c2) in enumerate(convs):
+                        last = m == len(convs) - 1
+                        if c2 is None:  # ResBlock2
+                            src = c1
+                            inp = y
+                        else:
+                            ops.conv(y, c1, out=tmp, pre_act=ops.ACT_LRELU, pre_slope=LRELU_SLOPE)
+                            src, inp = c2, tmp
+                        if last:  # xs += resblock(x); x = xs / num_kernels  (models.py:506-512)
+                            if streams and prev_acc is not None:
+                                st.wait_event(prev_acc)
+                            ops.conv(inp, src, res=y, out=acc, pre_act=ops.ACT_LRELU, pre_slope=LRELU_SLOPE, out_scale=1.0 / nk,
+                                     accumulate=j > 0)
+                            if streams:
+                                prev_acc = torch.cuda.Event()
+                                prev_acc.record(st)
+                        else:
+                            dst = ya if y is not ya else yb
+                            ops.conv(inp, src, res=y, out=dst, pre_act=ops.ACT_LRELU, pre_slope=LRELU_SLOPE)
+                            y = dst
+            if streams:
+                main.wait_event(prev_acc)
             x = acc
         # F.leaky_relu default slope 0.01 (models.py:513), conv_post (no bias), tanh
         return ops.conv(x, P["conv_post"], pre_act=ops.ACT_LRELU, pre_slope=0.01, act=ops.ACT_TANH)
+
+    def _rb_streams(self, device, nk):
+        """Side streams for the ResBlock chains of a vocoder stage (one per chain but the first, created once per model: the caching
+        allocator keeps a pool per stream), or None where the chains run one after the other (CPU / emulator, AICG_RB_STREAMS=0)."""
+        if device.type != "cuda" or nk < 2 or os.environ.get("AICG_RB_STREAMS", "1") == "0":
+            return None
+        have = getattr(self, "_rb_side", None)
+        if have is None or len(have) != nk - 1:
+            have = self._rb_side = [torch.cuda.Stream(device=device) for _ in range(nk - 1)]
+        return have
 
     def infer(self, phone, phone_lengths, pitch=None, nsff0=None, sid=None, max_len=None, noise_z=None, noise_src=None,
               phone_ct=None):

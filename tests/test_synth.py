@@ -68,6 +68,30 @@ def test_synth_40k_long_vs_oracle():
     assert (o.cpu() - ro).abs().max() < 1e-4
 
 
+@pytest.mark.gpu
+def test_resblock_chains_on_side_streams_are_bit_identical(monkeypatch):
+    """The vocoder's ResBlock chains run on their own streams with the accumulating convolutions ordered by events
+    (GeneratorNSF.forward, reference src/infer_pack/models.py:506-512): the waveform must equal the one-stream walk BIT FOR BIT,
+    call after call (a missed dependency would show as run-to-run differences)."""
+    import conftest
+    conftest._bind("hip")
+    d = conftest.Dev("hip")
+    cfg, T = weights.SYNTH_CFG_40K_V2, 900
+    sd = weights.synth_state_dict(cfg, 4321)
+    net = SynthesizerTrnMs768NSFsid(*cfg, is_half=False)
+    del net.enc_q
+    net.load_state_dict(sd, strict=False)
+    net.eval().to(d.device)
+    phone, pitch, f0, nz, ns = synth_inputs(cfg, T, 99)
+    run = lambda: net.infer(phone, torch.tensor([T]), pitch, f0, torch.tensor([1]), noise_z=nz, noise_src=ns)[0].clone()
+    monkeypatch.setenv("AICG_RB_STREAMS", "0")
+    one = run()
+    monkeypatch.setenv("AICG_RB_STREAMS", "1")
+    assert net._rb_streams(d.device, 3) is not None
+    for _ in range(4):
+        assert torch.equal(run(), one)
+
+
 def test_synth_default_noise_path_runs(dev):
     """Without injected noise the drop-in draws from torch's global RNG like the reference (models.py:748,368)."""
     cfg, T = weights.SYNTH_CFG_TINY, 8
