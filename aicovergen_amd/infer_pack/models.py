@@ -278,10 +278,11 @@ class _SynthesizerBase:
             x = ops.conv_transpose(x, pt, add=add, pre_act=ops.ACT_LRELU, pre_slope=LRELU_SLOPE)
             acc = torch.empty_like(x)
             # The num_kernels ResBlocks of a stage read the same x and are independent up to their last convolution, which adds into
-            # the shared sum (models.py:506-512).  On the GPU each chain runs on its own stream: a launch here is 2-24 rounds of
-            # workgroups over the chip, and its ragged last round (the 256-channel stage: 1 142 tiles on 512 slots = 2.2 rounds) runs
-            # under another chain's launch instead of leaving CUs idle.  The accumulating convolutions stay ordered k = 3, 7, 11 by
-            # events, so the sum is formed in the reference's order: output bit-identical to the one-stream walk (AICG_RB_STREAMS=0).
+            # the shared sum (models.py:506-512).  Opt-in (AICG_RB_STREAMS=1): each chain on its own stream, so that a launch's ragged
+            # last round (the 256-channel stage: 1 142 tiles on 512 slots = 2.2 rounds) could run under another chain's launch; the
+            # accumulating convolutions stay ordered k = 3, 7, 11 by events -- output bit-identical to the one-stream walk
+            # (tests/test_synth.py).  Measured (tools/kbench_rb_streams.py, round-robin): chunk loop 238.1 ms against 237.8 -- the
+            # launches do not overlap usefully (two resident workgroups per CU either way), so the one-stream walk stays the default.
             streams = self._rb_streams(x.device, nk)
             main = torch.cuda.current_stream(x.device) if streams else None
             bufs = [tuple(torch.empty_like(x) for _ in range(3)) for _ in range(nk if streams else 1)]
@@ -327,8 +328,8 @@ class _SynthesizerBase:
 
     def _rb_streams(self, device, nk):
         """Side streams for the ResBlock chains of a vocoder stage (one per chain but the first, created once per model: the caching
-        allocator keeps a pool per stream), or None where the chains run one after the other (CPU / emulator, AICG_RB_STREAMS=0)."""
-        if device.type != "cuda" or nk < 2 or os.environ.get("AICG_RB_STREAMS", "1") == "0":
+        allocator keeps a pool per stream), or None where the chains run one after the other (the default; CPU / emulator)."""
+        if device.type != "cuda" or nk < 2 or os.environ.get("AICG_RB_STREAMS", "0") != "1":
             return None
         have = getattr(self, "_rb_side", None)
         if have is None or len(have) != nk - 1:

@@ -1,4 +1,4 @@
-"""The vocoder's ResBlock chains on their own streams (AICG_RB_STREAMS=1, default) against the one-stream walk, round-robin on the bench track's
+"""The vocoder's ResBlock chains on their own streams (AICG_RB_STREAMS=1, opt-in) against the one-stream walk, round-robin on the bench track's
 RVC stage (VC.pipeline: HuBERT || f0 phase, then per chunk front + vocoder) and on one reference-sized synthesizer chunk."""
 import os, sys, time, statistics, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
