@@ -90,3 +90,56 @@ def test_g1_shuffle_on_gpu_at_mdx_level_size():
     y = ops.conv_transpose(x.to(dev), pt, act=ops.ACT_RELU, mul=skip.to(dev))
     assert _lib.last_launch() == "conv_g1_kernel", _lib.last_launch()
     assert rel_rms(y, F.relu(F.conv_transpose2d(x, wt, pt.bias.cpu(), stride=2)) * skip) < 1e-5
+
+
+def _g1_fuzz_case(dev, seed):
+    import random
+    rng = random.Random(seed)
+    torch.manual_seed(seed)
+    n = rng.choice([1, 1, 2, 3])
+    ci = rng.choice([9, 12, 16, 24, 40, 100, 130])   # (<= 8 channels on one side: the pointwise streaming kernel takes the layer)
+    co = rng.choice([33, 40, 64, 72, 128, 192, 200])
+    two_d = rng.random() < 0.4
+    h = rng.choice([2, 3, 5]) if two_d else 1
+    w = 4 * rng.choice([1, 2, 16, 33, 64, 65, 130])
+    tile = rng.choice([2, 3, 4])
+    x, wt = torch.randn(n, ci, h, w), torch.randn(co, ci, 1, 1) * 0.2
+    b = torch.randn(co) if rng.random() < 0.7 else None
+    pc = ops.PackedConv(wt, b, device=dev.device)
+    ref = F.conv2d(x, wt, b)
+    mode = rng.choice(["plain", "gelu", "res", "res_first", "accum", "pre", "tanh"])
+    xd = dev.t(x)
+    ops.gemm_tile = tile
+    try:
+        if mode == "gelu":
+            got, ref = ops.conv(xd, pc, act=ops.ACT_GELU), F.gelu(ref)
+        elif mode == "tanh":
+            got, ref = ops.conv(xd, pc, act=ops.ACT_TANH, out_scale=2.0), 2.0 * torch.tanh(ref)
+        elif mode == "res":
+            r = torch.randn_like(ref)
+            got, ref = ops.conv(xd, pc, res=dev.t(r), act=ops.ACT_RELU), F.relu(ref) + r
+        elif mode == "res_first":
+            r = torch.randn_like(ref)
+            got, ref = ops.conv(xd, pc, res=dev.t(r), act=ops.ACT_LRELU, act_slope=0.2, res_before_act=True), F.leaky_relu(ref + r, 0.2)
+        elif mode == "pre":
+            got, ref = ops.conv(xd, pc, pre_act=ops.ACT_LRELU, pre_slope=0.1), F.conv2d(F.leaky_relu(x, 0.1), wt, b)
+        elif mode == "accum":
+            y0 = torch.randn_like(ref)
+            got = dev.t(y0.clone())
+            ops.conv(xd, pc, out=got, accumulate=True, out_scale=0.5)
+            ref = y0 + 0.5 * ref
+        else:
+            got = ops.conv(xd, pc)
+        launched = _lib.last_launch()
+    finally:
+        ops.gemm_tile = 0
+    return (n, ci, co, h, w, tile, mode), launched, rel_rms(got, ref)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_g1_fuzz(dev, seed):
+    """Seeded random 1 x 1 layers (ragged M / K, map sizes from one quad to several tiles with a tail, several images, every epilogue mode)
+    on a forced tile of conv_g1 (aicg_conv_desc.gemm_tile: no process-wide switch needed), against torch."""
+    desc, launched, err = _g1_fuzz_case(dev, seed)
+    assert launched == "conv_g1_kernel", (desc, launched)
+    assert err < 1e-5, (desc, err)
