@@ -3,7 +3,7 @@
 #include "conv_ws3s.h"
 #include "conv_ws3w.h"
 #include "conv_w2d.h"
-#include "conv_g1.h"
+#include "conv_g1k.h"
 
 namespace aicg {
 
@@ -270,6 +270,19 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
                     else rc = run_g1_64x256(p, gst);
                 }
             }
+            if (rc <= 0) return rc;
+        }
+    }
+
+    // LDS-DMA staged k-tap 1-D convolution (conv_g1k.h): the vocoder's ResBlock layers.  aicg_conv_desc.gemm_tile: 2 / 3 force its
+    // 128 x 256 / 64 x 256 tile, 1 keeps the layer off it, 0 the policy
+    {
+        const long g1k = d->gemm_tile;
+        if (g1k != 1 && !p.wsplit && p.Cout_g > 32 && conv_g1k_applicable(p, pad_w_end)) {
+            hipStream_t gst = (hipStream_t)stream;
+            int rc = 1;
+            if (g1k == 2) rc = run_g1k_128x256(p, gst);
+            else if (g1k == 3) rc = run_g1k_64x256(p, gst);
             if (rc <= 0) return rc;
         }
     }

@@ -38,6 +38,91 @@ __device__ __forceinline__ void g1_wait_pieces() {   // at most N of this wave's
 #endif
 }
 
+// Epilogue shared by conv_g1_kernel and conv_g1k_kernel.  Register r of tile (i, j): row m_wave0 + 32 i + 8 (r >> 2) + 4 half + (r & 3),
+// position pos + j (pos = the first of this lane's four consecutive positions; HW % 4 == 0: a quad is inside the map or outside).
+// y = [y +] out_scale * (act(acc + bias [+ res]) [+ res | * res]); SHUF: the k = s = 2 ConvTranspose2d scatter.
+template <int TM, bool SHUF>
+__device__ __forceinline__ void g1_epilogue(const ConvArgs& p, f32x16 (&acc)[TM][4], int img, int m_wave0, int pos, int HW) {
+    const int lane = (int)(threadIdx.x & 63), half = lane >> 5;
+    const bool pos_ok = pos < HW;                                     // (HW % 4 == 0: a quad is inside the map or outside; no early exit --
+                                                                      //  every lane's bias register is a shuffle source)
+    // bias: the wave's rows are contiguous -- one coalesced load per 64 rows, every (tile, register) slot picks its value with a shuffle
+    constexpr int NBR = (TM * 32 + 63) / 64;
+    float breg[NBR];
+#pragma unroll
+    for (int t = 0; t < NBR; ++t) {
+        const int m = m_wave0 + 64 * t + lane;
+        breg[t] = (p.bias && m < p.Cout_g) ? p.bias[m] : 0.f;
+    }
+    auto body = [&](auto act_tag) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(act_tag)::value;
+        if constexpr (SHUF) {
+            // rows 4 co .. 4 co + 3 are the taps (dy, dx) of output channel co; positions (ho, wo .. wo + 3) -> rows 2 ho + dy, columns
+            // 2 wo .. 2 wo + 7: two float4 per (channel, dy)
+            const int ho = pos / p.Wo, wo = pos - ho * p.Wo;
+            const long y_pos = (long)img * p.y_sn + (long)(2 * ho) * p.y_sh + 2 * wo;
+            const long r_pos = (long)img * p.r_sn + (long)(2 * ho) * p.r_sh + 2 * wo;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int m0 = m_wave0 + i * 32 + 8 * q + 4 * half;
+                    float bb[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) bb[e] = __shfl(breg[i >> 1], (i & 1) * 32 + 8 * q + 4 * half + e, 64);
+                    if (m0 >= p.Cout_g || !pos_ok) continue;
+                    const long co = m0 >> 2;
+#pragma unroll
+                    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                        for (int hj = 0; hj < 2; ++hj) {
+                            float v[4] = {acc[i][2 * hj][4 * q + 2 * dy] + bb[2 * dy], acc[i][2 * hj][4 * q + 2 * dy + 1] + bb[2 * dy + 1],
+                                          acc[i][2 * hj + 1][4 * q + 2 * dy] + bb[2 * dy], acc[i][2 * hj + 1][4 * q + 2 * dy + 1] + bb[2 * dy + 1]};
+                            float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (p.res) rv = *reinterpret_cast<const float4*>(p.res + r_pos + co * p.r_sc + (long)dy * p.r_sh + 4 * hj);
+                            const float rr[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                float x = act_static<ACT>(v[t], p.act, p.act_slope);
+                                if (p.res) x = p.res_mul ? x * rr[t] : x + rr[t];
+                                v[t] = x * p.out_scale;
+                            }
+                            *reinterpret_cast<float4*>(p.y + y_pos + co * p.y_sc + (long)dy * p.y_sh + 4 * hj) = make_float4(v[0], v[1], v[2], v[3]);
+                        }
+                }
+        } else {
+            const long y_col = (long)img * p.y_sn + pos, r_col = (long)img * p.r_sn + pos;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m_wave0 + i * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+                    const float bv = __shfl(breg[i >> 1], (i & 1) * 32 + 8 * (r >> 2) + 4 * half + (r & 3), 64);
+                    if (m >= p.Cout_g || !pos_ok) continue;
+                    float v[4] = {acc[i][0][r] + bv, acc[i][1][r] + bv, acc[i][2][r] + bv, acc[i][3][r] + bv};
+                    float4 rv = make_float4(0.f, 0.f, 0.f, 0.f), yv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (p.res) rv = *reinterpret_cast<const float4*>(p.res + r_col + (long)m * p.r_sc);
+                    if (p.accumulate) yv = *reinterpret_cast<const float4*>(p.y + y_col + (long)m * p.y_sc);
+                    const float rr[4] = {rv.x, rv.y, rv.z, rv.w}, yy[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        float x = v[t];
+                        if (p.res_first) x += rr[t];
+                        x = act_static<ACT>(x, p.act, p.act_slope);
+                        if (!p.res_first) x += rr[t];
+                        v[t] = x * p.out_scale + yy[t];
+                    }
+                    *reinterpret_cast<float4*>(p.y + y_col + (long)m * p.y_sc) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+        }
+    };
+    if (p.act == AICG_ACT_NONE) body(std::integral_constant<int, 0>{});
+    else if (p.act == AICG_ACT_RELU) body(std::integral_constant<int, 1>{});
+    else if (p.act == AICG_ACT_LRELU) body(std::integral_constant<int, 2>{});
+    else if (!SHUF && p.act == AICG_ACT_GELU) body(std::integral_constant<int, 4>{});
+    else body(std::integral_constant<int, 3>{});
+}
+
 // SHUF: the kernel = stride = 2 ConvTranspose2d scatter (ConvArgs::shuffle == 2) with its additive / multiplicative skip operand.
 // WPS: waves per SIMD the register allocation is held to.
 // SPREAD: the DMA pieces of a stage go out one at a time between the MFMAs (see mma_group) instead of as one burst behind the barrier.
@@ -192,86 +277,7 @@ __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1_kernel(C
     w2d_fence();
     mma_group(a1, b1, std::false_type{}, false, nullptr);
 
-    // ---- epilogue.  Register r of tile (i, j): row m_wave0 + 32 i + 8 (r >> 2) + 4 half + (r & 3), position n_w + 4 l31 + j.
-    const int m_wave0 = m_base + wm * (TM * 32);
-    const int pos = n0 + wn * 128 + 4 * l31;                          // first of this lane's four positions
-    const bool pos_ok = pos < HW;                                     // (HW % 4 == 0: a quad is inside the map or outside; no early exit --
-                                                                      //  every lane's bias register is a shuffle source)
-    // bias: the wave's rows are contiguous -- one coalesced load per 64 rows, every (tile, register) slot picks its value with a shuffle
-    constexpr int NBR = (TM * 32 + 63) / 64;
-    float breg[NBR];
-#pragma unroll
-    for (int t = 0; t < NBR; ++t) {
-        const int m = m_wave0 + 64 * t + lane;
-        breg[t] = (p.bias && m < p.Cout_g) ? p.bias[m] : 0.f;
-    }
-    auto body = [&](auto act_tag) __attribute__((always_inline)) {
-        constexpr int ACT = decltype(act_tag)::value;
-        if constexpr (SHUF) {
-            // rows 4 co .. 4 co + 3 are the taps (dy, dx) of output channel co; positions (ho, wo .. wo + 3) -> rows 2 ho + dy, columns
-            // 2 wo .. 2 wo + 7: two float4 per (channel, dy)
-            const int ho = pos / p.Wo, wo = pos - ho * p.Wo;
-            const long y_pos = (long)img * p.y_sn + (long)(2 * ho) * p.y_sh + 2 * wo;
-            const long r_pos = (long)img * p.r_sn + (long)(2 * ho) * p.r_sh + 2 * wo;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int m0 = m_wave0 + i * 32 + 8 * q + 4 * half;
-                    float bb[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) bb[e] = __shfl(breg[i >> 1], (i & 1) * 32 + 8 * q + 4 * half + e, 64);
-                    if (m0 >= p.Cout_g || !pos_ok) continue;
-                    const long co = m0 >> 2;
-#pragma unroll
-                    for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                        for (int hj = 0; hj < 2; ++hj) {
-                            float v[4] = {acc[i][2 * hj][4 * q + 2 * dy] + bb[2 * dy], acc[i][2 * hj][4 * q + 2 * dy + 1] + bb[2 * dy + 1],
-                                          acc[i][2 * hj + 1][4 * q + 2 * dy] + bb[2 * dy], acc[i][2 * hj + 1][4 * q + 2 * dy + 1] + bb[2 * dy + 1]};
-                            float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if (p.res) rv = *reinterpret_cast<const float4*>(p.res + r_pos + co * p.r_sc + (long)dy * p.r_sh + 4 * hj);
-                            const float rr[4] = {rv.x, rv.y, rv.z, rv.w};
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) {
-                                float x = act_static<ACT>(v[t], p.act, p.act_slope);
-                                if (p.res) x = p.res_mul ? x * rr[t] : x + rr[t];
-                                v[t] = x * p.out_scale;
-                            }
-                            *reinterpret_cast<float4*>(p.y + y_pos + co * p.y_sc + (long)dy * p.y_sh + 4 * hj) = make_float4(v[0], v[1], v[2], v[3]);
-                        }
-                }
-        } else {
-            const long y_col = (long)img * p.y_sn + pos, r_col = (long)img * p.r_sn + pos;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m_wave0 + i * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-                    const float bv = __shfl(breg[i >> 1], (i & 1) * 32 + 8 * (r >> 2) + 4 * half + (r & 3), 64);
-                    if (m >= p.Cout_g || !pos_ok) continue;
-                    float v[4] = {acc[i][0][r] + bv, acc[i][1][r] + bv, acc[i][2][r] + bv, acc[i][3][r] + bv};
-                    float4 rv = make_float4(0.f, 0.f, 0.f, 0.f), yv = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (p.res) rv = *reinterpret_cast<const float4*>(p.res + r_col + (long)m * p.r_sc);
-                    if (p.accumulate) yv = *reinterpret_cast<const float4*>(p.y + y_col + (long)m * p.y_sc);
-                    const float rr[4] = {rv.x, rv.y, rv.z, rv.w}, yy[4] = {yv.x, yv.y, yv.z, yv.w};
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        float x = v[t];
-                        if (p.res_first) x += rr[t];
-                        x = act_static<ACT>(x, p.act, p.act_slope);
-                        if (!p.res_first) x += rr[t];
-                        v[t] = x * p.out_scale + yy[t];
-                    }
-                    *reinterpret_cast<float4*>(p.y + y_col + (long)m * p.y_sc) = make_float4(v[0], v[1], v[2], v[3]);
-                }
-        }
-    };
-    if (p.act == AICG_ACT_NONE) body(std::integral_constant<int, 0>{});
-    else if (p.act == AICG_ACT_RELU) body(std::integral_constant<int, 1>{});
-    else if (p.act == AICG_ACT_LRELU) body(std::integral_constant<int, 2>{});
-    else if (!SHUF && p.act == AICG_ACT_GELU) body(std::integral_constant<int, 4>{});
-    else body(std::integral_constant<int, 3>{});
+    g1_epilogue<TM, SHUF>(p, acc, img, m_base + wm * (TM * 32), n0 + wn * 128 + 4 * l31, HW);
 }
 
 // host side: does the layer have the form this kernel takes?  (1 x 1, unit stride, no padding, one group, no input activation
