@@ -274,8 +274,8 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
         }
     }
 
-    // LDS-DMA staged k-tap 1-D convolution (conv_g1k.h): the vocoder's ResBlock layers.  aicg_conv_desc.gemm_tile: 2 / 3 force its
-    // 128 x 256 / 64 x 256 tile, 1 keeps the layer off it, 0 the policy
+    // LDS-DMA staged k-tap 1-D convolution (conv_g1k.h): opt-in only -- aicg_conv_desc.gemm_tile 2 / 3 force its 128 x 256 / 64 x 256 tile.
+    // Measured on the vocoder's ResBlock layers (profiles/r04_kbench_g1k.txt) conv_ws3 wins by 10-25 %: no layer is routed here by policy
     {
         const long g1k = d->gemm_tile;
         if (g1k != 1 && !p.wsplit && p.Cout_g > 32 && conv_g1k_applicable(p, pad_w_end)) {
