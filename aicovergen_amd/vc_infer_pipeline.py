@@ -423,8 +423,12 @@ class VC(object):
         # (a helper thread fights the launch loop for the GIL).  AICG_OVERLAP_F0=0 restores the reference's serial order
         # (f0, then per chunk: features, synthesis).
         on_gpu = self._sync()
-        # (AICG_F0_SEGMENTS on the host: the CPU tests walk the same progressive schedule, with the streams and events as no-ops)
-        nseg = int(os.environ.get("AICG_F0_SEGMENTS", "0")) or (16 if world > 1 else 0)
+        # (AICG_F0_SEGMENTS on the host: the CPU tests walk the same progressive schedule, with the streams and events as no-ops;
+        #  "1" = the recurrence as one launch.)  One rank on a GPU takes the progressive schedule too since the f0 chain became the
+        #  longer branch of the phase (r4: HuBERT 74.9 ms, f0 79.4): the chunk loop then starts when HuBERT is done, on the middle chunks,
+        #  while the recurrence finishes the track's ends -- 718.7 -> 713.9 ms per 240 s track at 8 segments (4: 715.5, 16: 715.6).
+        env_seg = int(os.environ.get("AICG_F0_SEGMENTS", "0"))
+        nseg = env_seg or (16 if world > 1 else (8 if on_gpu else 0))
         overlap = (if_f0 == 1 and f0_method == "rmvpe" and (on_gpu or nseg > 1)
                    and os.environ.get("AICG_OVERLAP_F0", "1") != "0")
         feats_of = {}

@@ -131,11 +131,13 @@ def test_resample_sr_branch_vs_reference_golden(dev):
 
 
 def test_progressive_f0_schedule_is_bit_identical(dev, monkeypatch):
-    """Multi-GPU schedule: the BiGRU recurrence in segments (AICG_F0_SEGMENTS; on by default for world > 1), the pitch of
+    """Multi-GPU schedule: the BiGRU recurrence in segments (AICG_F0_SEGMENTS; the default for world > 1 and, since r4, for one
+    rank on a GPU; "1" = one launch), the pitch of
     a frame range published as soon as both directions have passed it, the chunks taken middle-out with a per-chunk wait.  On a
     6-chunk track the int16 output must equal the one-launch schedule's bit for bit, and the chunk order must really differ."""
     nets = weights.small_model_set(1234)
     audio = vocal_like(6.3, 16000, 1239)
+    monkeypatch.setenv("AICG_F0_SEGMENTS", "1")
     ref, _, vc0 = run(dev, nets, audio)
     assert vc0.last_profile["f0_progressive"] == 0.0
     monkeypatch.setenv("AICG_F0_SEGMENTS", "6")
