@@ -184,7 +184,7 @@ class E2E:
         cell = 1 << len(self.enc)
         halo = self.time_reach()
         per = ((T + world - 1) // world + cell - 1) // cell * cell      # frames per rank, whole cells
-        if world == 1 or per < 2 * halo:                                 # short tracks: the margins would dominate
+        if adist.single(world, group) or per < 2 * halo:                 # one rank / short tracks: the margins would dominate
             return self.features(mel)
         a, b = min(rank * per, T), min((rank + 1) * per, T)
         block = torch.zeros((mel.shape[1] * self.cnn.cout, per), dtype=torch.float32, device=mel.device)

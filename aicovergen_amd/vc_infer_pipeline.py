@@ -160,7 +160,7 @@ class VC(object):
         if not getattr(self, "_in_pipeline", False) or not (td.is_available() and td.is_initialized()):
             return _NO_GROUP if not explicit else None
         g = getattr(self, "_group", None)
-        if (td.get_world_size(g) if g is not None else td.get_world_size()) < 2:
+        if adist.single(td.get_world_size(g) if g is not None else td.get_world_size(), g):
             return _NO_GROUP if not explicit else None
         return g if (g is not None or not explicit) else td.group.WORLD
 

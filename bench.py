@@ -272,8 +272,12 @@ def main():
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)
     group = None
-    if world > 1:
+    # One rank normally has no process group.  AICG_DIST_BACKEND set explicitly under a launcher (RANK in the environment) creates the
+    # one-rank group anyway; together with AICG_FORCE_COLLECTIVES=1 every join of the step then runs through RCCL on a one-GPU box
+    # (profiles/r05_bench_c3_one_rank_rccl.json) -- the line says so in config.collectives
+    if world > 1 or (os.environ.get("AICG_DIST_BACKEND") and "RANK" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         backend = os.environ.get("AICG_DIST_BACKEND", "gloo" if emu else "nccl")   # "nccl" is RCCL on ROCm
         if backend == "nccl":
             td.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
@@ -338,7 +342,8 @@ def main():
             ops.conv_profile = ops.stage_profile = None
     dts = torch.tensor([dt], dtype=torch.float64, device=device)
     per_rank = [dt]
-    if world > 1:
+    have_group = td.is_available() and td.is_initialized()
+    if have_group:
         allt = [torch.empty_like(dts) for _ in range(world)]
         td.all_gather(allt, dts)
         per_rank = [float(t.item()) for t in allt]
@@ -346,9 +351,12 @@ def main():
     # where each rank's step went (seconds per step): own MDX windows incl. the stem all-gather, the all-gather alone, plan, HuBERT
     # with the f0 branch underneath, the wait for f0 behind it, the chunk loop, the chunk join, post -- so that a scaling curve says
     # which term grew
-    split_keys = ["mdx_s", "mdx_allgather_s", "plan_s", "f0_s", "f0_wait_s", "chunks_s", "join_s", "post_s"]
+    # (mdx_allgather_s, rvc_lengths_allgather_s, rvc_pieces_allgather_s: the collective alone, device drained on both sides --
+    #  RCCL time as opposed to waiting for the slowest rank, which is in the stage walls around it; `collectives` = how many ran)
+    split_keys = ["mdx_s", "mdx_allgather_s", "plan_s", "f0_s", "f0_wait_s", "chunks_s", "join_s", "rvc_lengths_allgather_s",
+                  "rvc_pieces_allgather_s", "post_s", "collectives"]
     per_rank_split = None
-    if world > 1:
+    if have_group:
         mine_split = torch.tensor([split.get(k, 0.0) for k in split_keys], dtype=torch.float64, device=device)
         alls = [torch.empty_like(mine_split) for _ in range(world)]
         td.all_gather(alls, mine_split)
@@ -380,6 +388,9 @@ def main():
                                    "one recurrence over the track, computed on every rank" % world,
                        "per_rank_seconds_per_step": [t / args.steps for t in per_rank],
                        "per_rank_wall_split_seconds_per_step": per_rank_split,
+                       "collectives": None if not have_group else "backend %s, world %d%s" % (
+                           td.get_backend(), world, ", one-rank joins forced through the collectives (AICG_FORCE_COLLECTIVES)"
+                           if world == 1 else ""),
                        "stage_seconds_per_step": {"hubert": stage[0] / args.steps, "f0": stage[1] / args.steps,
                                                   "synth": stage[2] / args.steps},
                        "wall_split_seconds_per_step": split,
@@ -425,7 +436,7 @@ def main():
             np.savez_compressed(args.dump, sep=sep.cpu().numpy()[:, ::7], out=out if out is not None else np.zeros(1))
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(res) + "\n").encode())
-    if world > 1:
+    if have_group:
         td.destroy_process_group()
 
 
