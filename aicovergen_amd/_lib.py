@@ -15,6 +15,7 @@ _HEADER = os.path.join(_HERE, "..", "include", "aicg.h")
 _DEFAULT = os.path.join(_HERE, "libaicg_hip.so")
 
 _lock = threading.Lock()
+_path = None
 _lib = None
 _backend = None  # "hip" | "emu"
 
@@ -68,7 +69,8 @@ def _load(path, backend):
     lib.aicg_last_error.argtypes = []
     lib.aicg_last_launch.restype = ctypes.c_char_p
     lib.aicg_last_launch.argtypes = []
-    _lib, _backend = lib, backend
+    global _path
+    _lib, _backend, _path = lib, backend, path
     return lib
 
 
@@ -82,6 +84,12 @@ def get():
 def backend():
     get()
     return _backend
+
+
+def get_path():
+    """File the bound library was loaded from (tests: development-only kernels exist in libaicg_hip_dev.so, not in the product)."""
+    get()
+    return _path
 
 
 def _use_library_for_tests(path, backend="emu"):

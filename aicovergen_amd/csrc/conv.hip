@@ -3,7 +3,10 @@
 #include "conv_ws3s.h"
 #include "conv_ws3w.h"
 #include "conv_w2d.h"
+#include "conv_g1.h"
+#ifdef AICG_DEV_SWITCHES
 #include "conv_g1k.h"
+#endif
 
 namespace aicg {
 
@@ -274,18 +277,18 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
         }
     }
 
-    // LDS-DMA staged k-tap 1-D convolution (conv_g1k.h): opt-in only -- aicg_conv_desc.gemm_tile 2 / 3 force its 128 x 256 / 64 x 256 tile.
-    // Measured on the vocoder's ResBlock layers (profiles/r04_kbench_g1k.txt) conv_ws3 wins by 10-25 %: no layer is routed here by policy
-    {
-        const long g1k = d->gemm_tile;
-        if (g1k != 1 && !p.wsplit && p.Cout_g > 32 && conv_g1k_applicable(p, pad_w_end)) {
-            hipStream_t gst = (hipStream_t)stream;
-            int rc = 1;
-            if (g1k == 2) rc = run_g1k_128x256(p, gst);
-            else if (g1k == 3) rc = run_g1k_64x256(p, gst);
+#ifdef AICG_DEV_SWITCHES
+    // LDS-DMA staged k-tap 1-D convolution (conv_g1k.h): DEVELOPMENT BUILDS ONLY (tools' private library, the CPU emulator) -- measured on
+    // the vocoder's ResBlock layers (profiles/r04_kbench_g1k.txt) conv_ws3 wins by 10-25 %, so the product library neither routes to it
+    // nor carries it.  aicg_conv_desc.gemm_tile 12 / 13 force its 128 x 256 / 64 x 256 tile (codes of their own: 2 / 3 / 4 select conv_g1
+    // tiles on 1 x 1 layers and must not reroute the k-tap layers).
+    if (d->gemm_tile == 12 || d->gemm_tile == 13) {
+        if (!p.wsplit && p.Cout_g > 32 && conv_g1k_applicable(p, pad_w_end)) {
+            const int rc = d->gemm_tile == 12 ? run_g1k_128x256(p, (hipStream_t)stream) : run_g1k_64x256(p, (hipStream_t)stream);
             if (rc <= 0) return rc;
         }
     }
+#endif
 
     // tile shape: the BM in {160, 128, 96, 64, 32} with the least padded M (larger BM on ties: one input patch
     // staging feeds more MFMAs), then enough workgroups to fill 256 CUs

@@ -281,7 +281,14 @@ class PackedConv:
             self.w_wino = pack_conv_weight(winograd_kernel(weight.detach().to(device=device, dtype=torch.float32)), 1, False)
             if winograd2d and self.cout % 48 == 0:
                 self.w_wino2 = winograd2d_image(weight.detach().to(device=device, dtype=torch.float32))
-                self.w_wino2q = winograd2d_image(weight.detach().to(device=device, dtype=torch.float32), quads=True)
+                # the quad-fragment image (16/9 of the weights in HBM) is read only under the dev switch winograd2d_quads: built on first
+                # use from the caller's own weight tensor (a reference, normally host memory), never for the product's layers
+                self._wino2q_src, self._wino2q_dev = weight.detach(), device
+
+    def wino2q(self):
+        if self.w_wino2q is None:
+            self.w_wino2q = winograd2d_image(self._wino2q_src.to(device=self._wino2q_dev, dtype=torch.float32), quads=True)
+        return self.w_wino2q
 
     def out_hw(self, h, w):
         pe = self.padding if self.padding_end is None else self.padding_end
@@ -405,7 +412,7 @@ def conv(x, pc, res=None, out=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NON
     if prof is not None and x.is_cuda:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _call("aicg_conv_forward", ctypes.addressof(d), _ptr(x4), _ptr((pc.w_wino2q if winograd2d_quads else pc.w_wino2) if wino2 else pc.w_wino if wino else pc.w), _ptr(b), _ptr(r4), _ptr(o4), _stream(x))
+    _call("aicg_conv_forward", ctypes.addressof(d), _ptr(x4), _ptr((pc.wino2q() if winograd2d_quads else pc.w_wino2) if wino2 else pc.w_wino if wino else pc.w), _ptr(b), _ptr(r4), _ptr(o4), _stream(x))
     if prof is not None and x.is_cuda:
         e1.record()
         prof.events.append((e0, e1))
@@ -636,7 +643,7 @@ def gru_timed_out():
     """True if any multi-workgroup GRU launch since the last call reported a partner-exchange timeout (the partner workgroup
     was not co-resident in time: a busy or shared GPU).  Call after the stream that ran them has been drained.  The result
     of such a launch is invalid; callers recompute with the single-workgroup kernel (`gru_bidir(two_workgroups=False)`)."""
-    pend, _gru_pending[:] = list(_gru_pending), []
+    pend, _gru_pending[:] = list(_gru_pending), []     # (the tensor references of the launches go with the list)
     bad = False
     for f, _ in pend:
         bad = bad or int(f.item()) != 0
@@ -651,10 +658,16 @@ def gru_check_pending():
 
 def _gru_repair_backlog():
     """A caller that never polls gru_timed_out(): bound the backlog (this synchronises) and REPAIR instead of failing -- every pending
-    launch whose flag is set is recomputed by the single-workgroup kernel into the same output tensor, on the stream it is used on."""
+    launch whose flag is set is recomputed by the single-workgroup kernel into the same output tensor, on the stream that is current
+    NOW.  The repair fixes `out` for LATER readers only: anything already derived from a flagged output (classifier, decode) stays
+    wrong and is not re-run -- which is why a flagged launch is also reported (warning), and why callers that can recompute their
+    dependants should poll gru_timed_out() themselves, as pipeline() and RMVPE.infer_from_audio do."""
+    import warnings
     pend, _gru_pending[:] = list(_gru_pending), []
     for f, (gi, whh_t, bhh, out, hidden) in pend:
         if int(f.item()) != 0:
+            warnings.warn("aicg_gru_bidir: a multi-workgroup launch timed out %d launches ago and nobody polled gru_timed_out(); its "
+                          "output is recomputed in place now -- results already derived from it are stale" % len(pend))
             _call("aicg_gru_bidir", _ptr(gi), _ptr(whh_t), _ptr(bhh), _ptr(out), hidden, gi.shape[1], _stream(gi))
 
 
@@ -715,6 +728,12 @@ class GruSegments:
             _call("aicg_gru_bidir_seg", _ptr(self.gi), _ptr(self.whh_t), _ptr(self.bhh), _ptr(self.out), self.hidden, self.T, s0, s1,
                   _ptr(self.state), _stream(self.gi))
         self.done = s1
+
+    def timed_out(self):
+        """The recurrence's error word as of NOW (a 4-byte read on the current stream; the segments may still be running on another):
+        nonzero = a partner exchange of the multi-workgroup kernel timed out, the output of that and every later segment is invalid
+        (later segments bail out early).  pipeline() polls it between chunks instead of synthesising a whole track from bad pitch."""
+        return bool(self.multi) and int(self.scratch[32 * self.hidden: 32 * self.hidden + 4].view(torch.int32).item()) != 0
 
     def ready(self):
         """[lo, hi): frames whose forward AND backward state exist after the steps queued so far (empty: lo >= hi)."""

@@ -284,8 +284,9 @@ class RMVPE:
         mel = self.mel_extractor(audio, center=True)
         n_frames = mel.shape[-1]
         mel = F.pad(mel, (0, 32 * ((n_frames - 1) // 32 + 1) - n_frames), mode="reflect")
-        self.model.progressive(mel, n_frames, nseg, lambda a, b, sal: on_f0(a, b, self._decode_device(sal, thred)[1]),
-                               two_workgroups, group)
+        # (last_segments: the recurrence's handle, for callers that poll its error word while it runs -- ops.GruSegments.timed_out)
+        self.last_segments = self.model.progressive(mel, n_frames, nseg, lambda a, b, sal: on_f0(a, b, self._decode_device(sal, thred)[1]),
+                                                    two_workgroups, group)
         return n_frames
 
     def infer_from_audio(self, audio, thred=0.03, group=None):

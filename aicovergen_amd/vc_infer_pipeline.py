@@ -199,7 +199,7 @@ class VC(object):
                 "f0_method %r needs parselmouth / pyworld, which are outside the MI355X hot path "
                 "(supported: rmvpe, mangio-crepe[-tiny], crepe[-tiny], hybrid[...] of the crepe methods)" % f0_method)
         tf0 = self.sr // self.window
-        f0 = np.asarray(f0, dtype=np.float64)
+        f0 = np.asarray(self._estimated_f0(0, len(f0), np.asarray(f0, dtype=np.float64)), dtype=np.float64)
         factor = pow(2, f0_up_key / 12)
         if inp_f0 is not None:
             f0 = f0 * factor
@@ -208,8 +208,22 @@ class VC(object):
             replace_f0 = np.interp(list(range(delta_t)), inp_f0[:, 0] * 100, inp_f0[:, 1])
             shape = f0[self.x_pad * tf0: self.x_pad * tf0 + len(replace_f0)].shape[0]
             f0[self.x_pad * tf0: self.x_pad * tf0 + len(replace_f0)] = replace_f0[:shape]
-        f0bak, coarse = ops.f0_coarse(torch.from_numpy(f0).to(self.device), factor, f0_mel_min, f0_mel_max)
+        f0bak, coarse = self._f0_tail(torch.from_numpy(f0).to(self.device), factor)
         return coarse.cpu().numpy(), f0bak.cpu().numpy()
+
+    def _estimated_f0(self, lo, hi, f0):
+        """Seam behind the estimator: EVERY f0 estimate passes through here before the key shift and the coarse quantiser -- the whole
+        track (numpy float64, lo = 0) from get_f0 under the serial / one-launch schedules, frame range [lo, hi) (device float64 tensor)
+        as the progressive schedule publishes it.  Identity; tests/test_bench_sizes.py replaces it to hold f0 fixed (the reference's own
+        track) under whichever schedule pipeline() takes."""
+        return f0
+
+    def _f0_tail(self, f0, factor):
+        """Key shift + mel-scale coarse bins of an f0 track (device float64) -> (f0 * factor float64, coarse int64), reference :360-370.
+        The one place both schedules quantise: get_f0 (whole track) and the progressive schedule's per-range callback."""
+        f0_mel_min = 1127 * np.log(1 + 50 / 700)
+        f0_mel_max = 1127 * np.log(1 + 1100 / 700)
+        return ops.f0_coarse(f0, factor, f0_mel_min, f0_mel_max)
 
     # ---- one chunk ----------------------------------------------------------------------------------------------
     def vc(self, model, net_g, sid, audio0, pitch, pitchf, times, index, big_npy, index_rate, version, protect,
@@ -433,6 +447,8 @@ class VC(object):
                    and os.environ.get("AICG_OVERLAP_F0", "1") != "0")
         feats_of = {}
         f0_wait = 0.0
+        gru_seg = None        # progressive f0: the recurrence's handle (its exchange-timeout word is polled between chunks)
+        f0_bad = False
         marks = []            # progressive f0: (first frame, end frame, event) -- the frame range whose pitch exists once the event has fired
         progressive = False
         if overlap:
@@ -449,21 +465,25 @@ class VC(object):
             # one upload of the padded track: a pageable host->device copy on the default stream waits for the whole device,
             # side stream included, so the chunk loop below must not issue any
             pad_dev = audio_pad.float()
+            # Progressive f0 (see below): the device-resident pitch tracks are created and filled on `main` BEFORE the side stream forks
+            # from it -- on_f0 writes slices of them on `side`, and a fill that could run after such a write would erase it
+            progressive = nseg > 1 and inp_f0 is None
+            if progressive:
+                pitch = torch.ones((1, p_len), dtype=torch.long, device=self.device)
+                pitchf = torch.zeros((1, p_len), dtype=torch.float32, device=self.device)
             side.wait_stream(main)
             tf0 = ttime()
             # Progressive f0 (multi-GPU: every rank runs the whole-track BiGRU, N x 32 ms for N x 240 s): the recurrence is queued in
             # segments, and the pitch of a frame range exists as soon as BOTH directions have passed it -- the middle of the track at
             # half the recurrence time, its ends last.  The chunk loop below then takes this rank's chunks middle-out and waits per
             # chunk (events), not for the whole track.  Same values as the one-launch form (GruSegments); the host never sees f0.
-            progressive = nseg > 1 and inp_f0 is None
+            # NOTE: this schedule never calls get_f0 (an override of VC.get_f0 is bypassed; the estimate passes _estimated_f0 and the
+            # shared _f0_tail instead); an f0 curve file (inp_f0) keeps the one-launch schedule, whose get_f0 splices it.
             if progressive:
-                f0_mel_min, f0_mel_max = 1127 * np.log(1 + 50 / 700), 1127 * np.log(1 + 1100 / 700)
-                pitch = torch.ones((1, p_len), dtype=torch.long, device=self.device)
-                pitchf = torch.zeros((1, p_len), dtype=torch.float32, device=self.device)
                 cover = [p_len, 0]
 
                 def on_f0(lo, hi, f0, _factor=pow(2, f0_up_key / 12)):
-                    f0bak, coarse = ops.f0_coarse(f0, _factor, f0_mel_min, f0_mel_max)
+                    f0bak, coarse = self._f0_tail(self._estimated_f0(lo, hi, f0), _factor)
                     hi2 = min(hi, p_len)
                     if lo < hi2:
                         pitch[0, lo:hi2] = coarse[: hi2 - lo]
@@ -475,6 +495,7 @@ class VC(object):
 
                 with (torch.cuda.stream(side) if on_gpu else side):
                     self._rmvpe().infer_progressive(pad_dev, 0.03, nseg, on_f0, group=self._rmvpe_group())
+                gru_seg = self._rmvpe().last_segments
             else:
                 with (torch.cuda.stream(side) if on_gpu else side):
                     f0_dev = self._rmvpe().infer_from_audio_device(pad_dev, thred=0.03, group=self._rmvpe_group())
@@ -483,6 +504,8 @@ class VC(object):
             feats_of = dict(zip(mine, many))
             main.synchronize()
             tf1 = ttime()
+            if progressive and gru_seg.timed_out():    # an early exchange timeout: do not synthesise a whole track from invalid pitch
+                f0_bad = True
             if not progressive:
                 side.synchronize()
                 main.wait_stream(side)
@@ -561,6 +584,8 @@ class VC(object):
                 torch.cuda.synchronize()
 
         for k, ci in enumerate(order):
+            if f0_bad:
+                break
             s, e = bounds[ci]
             pc, pcf = chunk_pitch(ci)
             if two_streams:
@@ -587,10 +612,13 @@ class VC(object):
                 out = self.vc(model, net_g, sid, audio_pad[s:e], pc, pcf, times, index, big_npy, index_rate, version, protect,
                               noise=noise, keep_on_device=True)
             pieces[ci] = out[self.t_pad_tgt: -self.t_pad_tgt]
+            if progressive and gru_seg.timed_out():    # polled per chunk (4 bytes): at most one chunk is synthesised from bad pitch
+                f0_bad = True
         if progressive:
             if on_gpu:
                 torch.cuda.synchronize()
-            if ops.gru_timed_out():
+            fronts.clear()
+            if ops.gru_timed_out() or f0_bad:
                 # the multi-workgroup recurrence starved of its partners (a busy or shared GPU): this rank's f0 is invalid.  Recompute
                 # it locally on the single-workgroup kernel (no collective: the other ranks may be fine) and redo this rank's chunks
                 f0_host = self._rmvpe().infer_from_audio_device(audio_pad.float(), thred=0.03, two_workgroups=False).cpu().numpy()

@@ -134,9 +134,9 @@ typedef struct aicg_conv_desc {
     int32_t gemm_tile;            /* 1 x 1 layers the LDS-DMA staged GEMM can take (csrc/conv_g1.h: unit stride, no padding, one group, no
                                      input activation but a leaky ReLU, contiguous 16-byte-aligned maps of a multiple of 4 positions): 0 the library's
                                      policy; 1 never that kernel; 2 / 3 / 4 its 128 x 256 / 64 x 256 / 192 x 256 tile (rows x positions
-                                     per workgroup).  On a 1-D k-tap layer (unit stride, one group, output length = input length, a multiple
-                                     of 4) 2 / 3 select the same tiles of csrc/conv_g1k.h (opt-in: measured slower than the default kernels
-                                     on the vocoder's layers).  Layers neither kernel can take ignore the field */
+                                     per workgroup).  Layers that kernel cannot take ignore the field.  (Development builds only: 12 / 13 force
+                                     the k-tap 1-D variant csrc/conv_g1k.h -- measured slower than the default kernels on the vocoder's
+                                     layers, not in the product library) */
 } aicg_conv_desc;
 
 int aicg_conv_bkc(int taps);

@@ -2,7 +2,13 @@
 container only) on seeded parameters from synthetic/weights.py and seeded inputs.  The fixtures pin the oracle
 (tests/test_oracle_golden.py) and travel to the GPU box, where /root/reference does not exist.
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py                 network-level fixtures + the small pipeline (overwrites)
+    python tests/golden/make_golden.py c1 | branches   the BASELINE C1 run / the f0-file and resample_sr branches (overwrites)
+    python tests/golden/make_golden.py --check [c1|branches|all]
+        regenerate into a TEMPORARY directory and print, per array, the distance to the committed fixture -- nothing is overwritten.
+        The network-level fixtures reproduce bit for bit on any host; the VC.pipeline ones only up to the host's oneDNN summation order
+        (thread count / CPU model move hundreds of int16 samples by one LSB; VERDICT r4 measured C1 at 1.04e-4 relative RMS, 8 LSB,
+        94.8 % <= 1 LSB between two Xeons) -- so a verifier compares distances, not checksums.
 """
 import contextlib
 import os
@@ -12,6 +18,7 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT_DIR = HERE          # --check: a temporary directory
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference/src"
 sys.path.insert(0, ROOT)
@@ -57,7 +64,7 @@ def make_synth(name, cfg, T, seed, variant="768f0"):
             o, _, (z, z_p, m_p, logs_p) = net.infer(phone, torch.tensor([T]), pitch, f0, sid)
         else:
             o, _, (z, z_p, m_p, logs_p) = net.infer(phone, torch.tensor([T]), sid)
-    np.savez_compressed(os.path.join(HERE, name + ".npz"), cfg_T=np.array([T]), seed=np.array([seed]),
+    np.savez_compressed(os.path.join(OUT_DIR, name + ".npz"), cfg_T=np.array([T]), seed=np.array([seed]),
                         audio=o[0, 0].numpy(), z=z[0].numpy(), m_p=m_p[0].numpy(), logs_p=logs_p[0].numpy())
     print(name, "audio", tuple(o.shape), float(o.abs().max()), float(o.pow(2).mean().sqrt()))
 
@@ -79,7 +86,7 @@ def make_hubert(name, cfg, seconds, seed):
     with torch.no_grad():
         out = m(wav, output_hidden_states=True)
     l9 = out.hidden_states[min(9, cfg["layers"])]
-    np.savez_compressed(os.path.join(HERE, name + ".npz"), seed=np.array([seed]), seconds=np.array([seconds]),
+    np.savez_compressed(os.path.join(OUT_DIR, name + ".npz"), seed=np.array([seed]), seconds=np.array([seconds]),
                         last=out.last_hidden_state[0].numpy(), layer9=l9[0].numpy())
     print(name, tuple(out.last_hidden_state.shape))
 
@@ -109,7 +116,7 @@ def make_rmvpe(name, cfg, seconds, seed):
     with torch.no_grad():
         mel = r.mel_extractor(torch.from_numpy(audio)[None], center=True)
         hidden = r.mel2hidden(mel)[0].numpy()
-    np.savez_compressed(os.path.join(HERE, name + ".npz"), seed=np.array([seed]), seconds=np.array([seconds]),
+    np.savez_compressed(os.path.join(OUT_DIR, name + ".npz"), seed=np.array([seed]), seconds=np.array([seconds]),
                         f0=f0, hidden=hidden.astype(np.float16 if hidden.size > 60000 else np.float32),
                         argmax=hidden.argmax(1).astype(np.int16), mel=mel[0].numpy().astype(np.float32))
     print(name, hidden.shape, float((f0 > 0).mean()))
@@ -229,12 +236,67 @@ def make_pipeline(name, seconds, seed, full=False, x=(1, 1, 1, 2), f0_rows=None,
     if full:
         extra.update(coarse=f0_seen["coarse"].astype(np.int16), f0=f0_seen["f0"].astype(np.float64), x=np.array(x),
                      ref_cpu_seconds=np.array([time.time() - t0]), ref_threads=np.array([torch.get_num_threads()]))
-    np.savez_compressed(os.path.join(HERE, name + ".npz"), seed=np.array([seed]), seconds=np.array([seconds]), audio=out, **extra)
+    np.savez_compressed(os.path.join(OUT_DIR, name + ".npz"), seed=np.array([seed]), seconds=np.array([seconds]), audio=out, **extra)
     print(name, out.shape, out.dtype, int(np.abs(out).max()), "%.1f s" % (time.time() - t0))
+
+
+def compare_with_committed(tmp):
+    """Per array of every regenerated fixture: distance to the committed one (floats: max |diff| and relative RMS; integers: samples
+    that differ, largest difference, share within 1 LSB).  Timing records (ref_cpu_seconds, ref_threads) are reported, not compared."""
+    worst = 0
+    for f in sorted(os.listdir(tmp)):
+        new, old = np.load(os.path.join(tmp, f)), np.load(os.path.join(HERE, f))
+        print(f)
+        for k in new.files:
+            a, b = new[k], old[k]
+            if k in ("ref_cpu_seconds", "ref_threads"):
+                print("   %-12s regenerated %s, committed %s (not compared)" % (k, a.tolist(), b.tolist()))
+                continue
+            if a.shape != b.shape:
+                print("   %-12s SHAPE %s vs committed %s" % (k, a.shape, b.shape))
+                worst = 2
+                continue
+            if np.array_equal(a, b):
+                print("   %-12s bit-identical %s %s" % (k, a.dtype, a.shape))
+                continue
+            worst = max(worst, 1)
+            d = np.abs(a.astype(np.float64) - b.astype(np.float64))
+            if np.issubdtype(a.dtype, np.integer):
+                rel = np.sqrt((d ** 2).sum() / max((b.astype(np.float64) ** 2).sum(), 1e-300))
+                print("   %-12s %d of %d differ, max %d, <= 1 on %.4f, rel rms %.3e" % (k, int((d > 0).sum()), d.size, int(d.max()),
+                                                                                      float((d <= 1).mean()), rel))
+            else:
+                rel = np.sqrt((d ** 2).sum() / max((b.astype(np.float64) ** 2).sum(), 1e-300))
+                print("   %-12s max |diff| %.3e, rel rms %.3e" % (k, d.max(), rel))
+    print("summary:", {0: "every array bit-identical", 1: "differences listed above (pipeline fixtures: host-dependent fp32 summation order)",
+                       2: "SHAPE MISMATCH"}[worst])
+    return worst
 
 
 if __name__ == "__main__":
     from synthetic import weights
+    if "--check" in sys.argv:
+        import tempfile
+        what = [a for a in sys.argv[1:] if a != "--check"] or ["nets"]
+        with tempfile.TemporaryDirectory() as tmp:
+            OUT_DIR = tmp
+            if "nets" in what or "all" in what:
+                make_synth("synth_tiny_T24", weights.SYNTH_CFG_TINY, 24, 1234)
+                make_synth("synth_40k_T16", weights.SYNTH_CFG_40K_V2, 16, 1234)
+                make_synth("synth_tiny_v1_T24", weights.SYNTH_CFG_TINY, 24, 1234, variant="256f0")
+                make_synth("synth_tiny_nono_T24", weights.SYNTH_CFG_TINY, 24, 1234, variant="768nono")
+                make_hubert("hubert_tiny_1s", weights.HUBERT_TINY, 1.0, 1234)
+                make_hubert("hubert_base_1s", weights.HUBERT_BASE, 1.0, 1234)
+                make_rmvpe("rmvpe_tiny_1s", weights.RMVPE_TINY, 1.0, 1234)
+                make_rmvpe("rmvpe_full_1s", weights.RMVPE_FULL, 1.0, 1234)
+                make_pipeline("pipeline_small_2p6s", 2.6, 1234)
+            if "branches" in what or "all" in what:
+                rows = [(0.10 + 0.05 * i, 180.0 + 40.0 * np.sin(0.7 * i) + 3.0 * i) for i in range(24)]
+                make_pipeline("pipeline_small_f0file", 2.6, 1234, f0_rows=rows)
+                make_pipeline("pipeline_small_resample32k", 2.6, 1234, resample_sr=32000)
+            if "c1" in what or "all" in what:
+                make_pipeline("pipeline_c1_30s", 30.0, 1234, full=True, x=(3, 10, 60, 65))
+            sys.exit(2 if compare_with_committed(tmp) == 2 else 0)
     if len(sys.argv) > 1 and sys.argv[1] == "c1":
         # BASELINE config C1: 30 s mono 16 kHz through the reference's own VC.pipeline on the CPU, full-size networks,
         # main.py's chunk preset (one 576 000-sample padded chunk)

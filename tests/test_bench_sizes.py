@@ -106,14 +106,18 @@ def test_c1_pipeline_vs_reference_golden():
     assert np.array_equal(coarse[:n], g64["coarse"][:n])
 
 
-def test_c1_pipeline_with_the_references_f0_injected(monkeypatch):
+@pytest.mark.parametrize("schedule", ["default", "one_launch"])
+def test_c1_pipeline_with_the_references_f0_injected(monkeypatch, schedule):
     """BASELINE C1 with the chaotic part held fixed.  The free-running test above has to allow 1e-3: RMVPE's
     f0 agrees with the reference's to 2.5e-7, but the vocoder's harmonic source integrates f0 over the whole 36 s chunk, so
     equally accurate f0 roundings give waveforms 1.2e-4 ... 4.7e-4 apart.  Here the REFERENCE's own f0 track
     (gold["f0"], what its get_f0 returned) replaces the estimator's output; everything else -- filtfilt, HuBERT, feature
     plumbing, coarse bins, text encoder, flow, SineGen, vocoder, RMS mix, int16 -- is this implementation.  A regression in any
     of those can no longer hide under the f0 -> phase sensitivity: the waveform must sit at accumulation-order distance from
-    the reference's."""
+    the reference's.
+    Both schedules (VERDICT r4 "missing" #5): "default" is what bench.py times -- on a GPU the PROGRESSIVE schedule (recurrence in 8
+    segments, pitch published per frame range on the side stream, get_f0 never called); "one_launch" (AICG_F0_SEGMENTS=1) asks get_f0
+    for the whole track.  The injection sits in VC._estimated_f0, the seam every estimate passes under either schedule."""
     from test_pipeline import build, noise_fn_for
     gold = np.load(os.path.join(GOLD, "pipeline_c1_30s.npz"))
     seed, x = int(gold["seed"][0]), tuple(int(v) for v in gold["x"])
@@ -121,25 +125,51 @@ def test_c1_pipeline_with_the_references_f0_injected(monkeypatch):
     audio = vocal_like(float(gold["seconds"][0]), 16000, seed + 5)
     import conftest
     dev = conftest.Dev("hip")
-    monkeypatch.setenv("AICG_F0_SEGMENTS", "1")   # the one-launch schedule: the only one that asks get_f0 (the hook below) for the track
+    if schedule == "one_launch":
+        monkeypatch.setenv("AICG_F0_SEGMENTS", "1")
+    else:
+        monkeypatch.delenv("AICG_F0_SEGMENTS", raising=False)
     vc, hub, net_g, tgt_sr = build(dev, nets, x)
-    orig = vc.get_f0
-    seen = {}
+    ranges = []
 
-    def with_reference_f0(*a, **k):
-        k["_raw_f0"] = gold["f0"].copy()
-        seen["coarse"], seen["f0"] = orig(*a, **k)
-        return seen["coarse"], seen["f0"]
-    vc.get_f0 = with_reference_f0
+    def reference_f0(lo, hi, f0):
+        ranges.append((lo, hi))
+        g = gold["f0"][lo:hi].astype(np.float64)
+        assert len(g) >= min(hi, len(gold["f0"])) - lo
+        if torch.is_tensor(f0):      # progressive schedule: a frame range on the device
+            out = f0.clone()
+            out[: len(g)] = torch.from_numpy(g).to(f0.device)
+            return out
+        out = np.array(f0, dtype=np.float64)
+        out[: len(g)] = g
+        return out
+    vc._estimated_f0 = reference_f0
+    tails = []
+    orig_tail = vc._f0_tail
+
+    def spy_tail(f0, factor):
+        f0bak, coarse = orig_tail(f0, factor)
+        tails.append((ranges[-1], coarse))
+        return f0bak, coarse
+    vc._f0_tail = spy_tail
     out = vc.pipeline(hub, net_g, 0, audio, "x.wav", [0, 0, 0], 0, "rmvpe", "", 0.5, 1, 3, tgt_sr, 0, 0.25, "v2", 0.33, 128,
                       noise_fn=noise_fn_for(nets))
+    assert vc.last_profile["f0_progressive"] == (1.0 if schedule == "default" else 0.0)
+    if schedule == "default":
+        assert len(ranges) > 2 and ranges[0][0] > 0          # the middle of the track first, in several ranges
+    else:
+        assert ranges == [(0, ranges[0][1])]
     ref = gold["audio"]
-    n = min(len(seen["coarse"]), len(gold["coarse"]))
-    assert np.array_equal(seen["coarse"][:n], gold["coarse"][:n])      # same f0 in -> the quantiser must give the same bins: bit-exact
+    # same f0 in -> the quantiser must give the same bins: bit-exact, range by range
+    n = len(gold["coarse"])
+    for (lo, hi), coarse in tails:
+        m = min(hi, n) - lo
+        if m > 0:
+            assert np.array_equal(coarse[:m].cpu().numpy(), gold["coarse"][lo:lo + m])
     diff = np.abs(out.astype(np.int32) - ref.astype(np.int32))
     rel = np.sqrt(np.sum(diff.astype(np.float64) ** 2) / np.sum(ref.astype(np.float64) ** 2))
-    print("C1, reference f0 injected: rel rms %.3e, max |diff| %d of peak %d, <= 1 LSB on %.5f, exact on %.4f"
-          % (rel, diff.max(), np.abs(ref).max(), (diff <= 1).mean(), (diff == 0).mean()))
+    print("C1, reference f0 injected, %s schedule (%d f0 range(s)): rel rms %.3e, max |diff| %d of peak %d, <= 1 LSB on %.5f, exact on %.4f"
+          % (schedule, len(ranges), rel, diff.max(), np.abs(ref).max(), (diff <= 1).mean(), (diff == 0).mean()))
     # SURVEY 8(d)'s end-to-end bar, reachable once the f0 -> phase path is held fixed: <= 1 LSB on >= 99.9 % of the samples.
     # Measured (round 4): max |diff| 1 LSB, <= 1 LSB on 100.000 %, exact on 93.8 %, rel rms 3.46e-5 -- which IS that 6.2 % of
     # one-LSB flips of the truncating int16 cast (q of the samples off by one LSB give sqrt(q) / rms(ref) = 3.5e-5 at q = 0.062);

@@ -1,5 +1,7 @@
 """The LDS-DMA staged k-tap 1-D convolution (csrc/conv_g1k.h: the vocoder's ResBlock layers, reference src/infer_pack/modules.py:299-312)
-against torch fp32, forced per launch through aicg_conv_desc.gemm_tile (2 = 128 x 256, 3 = 64 x 256 tile): every kernel size / dilation of
+against torch fp32, forced per launch through aicg_conv_desc.gemm_tile (12 = 128 x 256, 13 = 64 x 256 tile; development builds only:
+the kernel measured 10-25 % slower than conv_ws3 on these layers and is not in the product library, so the hardware variants of these
+tests skip unless a development library is bound): every kernel size / dilation of
 the ResBlocks and more, window shifts of every residue mod 4, ragged channels, tiles with a tail, several images, every epilogue mode.
 Tolerance: relative RMS <= 1e-5 (same fp32 products, different summation order)."""
 import random
@@ -13,6 +15,8 @@ from conftest import rel_rms
 
 
 def _run(dev, n, ci, co, k, d, T, tile, mode, pad=None, seed=0):
+    if dev.kind == "hip" and not _lib.get_path().endswith("_dev.so"):
+        pytest.skip("conv_g1k is compiled into development builds only (DESIGN 2.11)")
     torch.manual_seed(seed)
     pad = (k - 1) * d // 2 if pad is None else pad
     pad_end = (k - 1) * d - pad
@@ -44,7 +48,7 @@ def _run(dev, n, ci, co, k, d, T, tile, mode, pad=None, seed=0):
     return rel_rms(got, ref)
 
 
-@pytest.mark.parametrize("tile", [2, 3])
+@pytest.mark.parametrize("tile", [12, 13])
 @pytest.mark.parametrize("k,d", [(3, 1), (3, 3), (3, 5), (7, 1), (7, 3), (7, 5), (11, 1), (11, 3), (11, 5), (2, 1), (5, 2), (4, 3)])
 def test_g1k_resblock_geometries(dev, tile, k, d):
     """The vocoder's (kernel, dilation) pairs and a few others (even kernels: asymmetric padding), 64 = 64 channels, a map of one full tile
@@ -66,7 +70,7 @@ def test_g1k_fuzz(dev, seed):
     T = 4 * rng.choice([3, 16, 64, 65, 97, 130, 257])
     pad = rng.randint(0, (k - 1) * d)
     mode = rng.choice(["plain", "act", "accum"] + (["resblock"] if co == ci else []))
-    tile = rng.choice([2, 3])
+    tile = rng.choice([12, 13])
     err = _run(dev, n, ci, co, k, d, T, tile, mode, pad=pad, seed=seed)
     assert err < 1e-5, ((n, ci, co, k, d, T, pad, mode, tile), err)
 
@@ -75,7 +79,7 @@ def test_g1k_leaves_other_layers_alone(dev):
     """Strided, grouped, unaligned or length-changing layers are not the kernel's: the forced tile is ignored and the usual kernels run."""
     torch.manual_seed(1)
     x, w = torch.randn(1, 32, 258), torch.randn(64, 32, 3) * 0.2          # 258 % 4 != 0
-    ops.gemm_tile = 2
+    ops.gemm_tile = 12
     try:
         y = ops.conv(dev.t(x), ops.PackedConv(w, None, padding=1, device=dev.device))
         assert _lib.last_launch() != "conv_g1k_kernel"

@@ -130,11 +130,14 @@ def test_resample_sr_branch_vs_reference_golden(dev):
     assert diff.max() <= 3 and (diff <= 1).mean() >= 0.999
 
 
-def test_progressive_f0_schedule_is_bit_identical(dev, monkeypatch):
+def test_progressive_f0_schedule_matches_one_launch(dev, monkeypatch):
     """Multi-GPU schedule: the BiGRU recurrence in segments (AICG_F0_SEGMENTS; the default for world > 1 and, since r4, for one
     rank on a GPU; "1" = one launch), the pitch of
     a frame range published as soon as both directions have passed it, the chunks taken middle-out with a per-chunk wait.  On a
-    6-chunk track the int16 output must equal the one-launch schedule's bit for bit, and the chunk order must really differ."""
+    6-chunk track the int16 output must equal the one-launch schedule's -- BIT FOR BIT on the emulator (one tile path per layer);
+    on the hardware to <= 1 LSB on 99.9 % of the samples and never more than 3 LSB: the recurrence itself is bit-identical in segments
+    (tests/test_hubert_rmvpe.py), but the classifier GEMM over a frame RANGE may be routed to other tiles than over the whole track,
+    i.e. another fp32 summation order of the salience -- and the chunk order must really differ."""
     nets = weights.small_model_set(1234)
     audio = vocal_like(6.3, 16000, 1239)
     monkeypatch.setenv("AICG_F0_SEGMENTS", "1")
@@ -160,6 +163,38 @@ def test_progressive_f0_schedule_is_bit_identical(dev, monkeypatch):
     _, audio_pad, opt_ts, _ = vc.plan(audio)
     bounds = vc.chunk_bounds(audio_pad, opt_ts)
     assert len(bounds) >= 5 and seen != [e - s for s, e in bounds] and sorted(seen) == sorted(e - s for s, e in bounds)
+
+
+def test_every_f0_estimate_passes_the_seam_under_both_schedules(dev, monkeypatch):
+    """VC._estimated_f0 (the seam tests/test_bench_sizes.py injects the reference's f0 through): called once with the whole track under the
+    one-launch schedule, range by range -- middle first, disjoint, covering every pitch frame -- under the progressive one; replacing
+    the estimate there changes the output under either schedule, and a constant track gives the same output under both."""
+    nets = weights.small_model_set(1234)
+    audio = vocal_like(6.3, 16000, 1239)
+    outs = {}
+    for nseg in ("1", "6"):
+        monkeypatch.setenv("AICG_F0_SEGMENTS", nseg)
+        vc, hub, net_g, tgt_sr = build(dev, nets, (1, 1, 1, 2))
+        seen = []
+
+        def flat(lo, hi, f0, _seen=seen):
+            _seen.append((lo, hi, len(f0)))
+            return (torch.full_like(f0, 220.0) if torch.is_tensor(f0) else np.full_like(f0, 220.0))
+        vc._estimated_f0 = flat
+        outs[nseg] = vc.pipeline(hub, net_g, 0, audio, "x.wav", [0, 0, 0], 0, "rmvpe", "", 0.5, 1, 3, tgt_sr, 0, 0.25, "v2", 0.33, 128,
+                                 noise_fn=noise_fn_for(nets))
+        _, audio_pad, _, p_len = vc.plan(audio)
+        if nseg == "1":
+            assert len(seen) == 1 and seen[0][0] == 0 and seen[0][2] >= p_len
+        else:
+            assert len(seen) > 2 and seen[0][0] > 0 and all(hi - lo == n for lo, hi, n in seen)
+            cov = np.zeros(max(hi for _, hi, _ in seen), dtype=int)
+            for lo, hi, _ in seen:
+                cov[lo:hi] += 1
+            assert np.all(cov[:p_len] == 1)
+    assert np.array_equal(outs["1"], outs["6"])          # same (constant) pitch in -> same waveform out, whatever the schedule
+    ref, _, _ = run(dev, nets, audio)
+    assert not np.array_equal(outs["1"], ref)
 
 
 def assert_bins_agree(coarse, f0, want_coarse, want_f0, want_salience, max_rate=0.002):

@@ -1,0 +1,134 @@
+"""Is the HIP f0 error on BASELINE C1 a BIAS or noise?  (VERDICT r4 weak #1 / next #3b.)
+
+Free-running C1 sits 4.5-5.5e-4 relative RMS from the reference's waveform while the reference sits 1.0-1.8e-4 from itself (other host)
+and from float64 -- with f0 tracks that are equally accurate (2.3-2.6e-7 relative RMS against float64).  The vocoder's harmonic source
+integrates f0 (SineGen: phase[n] = sum f0 / sr, reference src/infer_pack/models.py:320-370), so what reaches the waveform is the RUNNING
+SUM of the f0 error, and a bias would integrate linearly where noise grows as sqrt(t).  This tool measures exactly that, for three
+tracks over the same 3 601 frames:
+
+    HIP (this run, default progressive schedule)   |   the reference's own fp32 CPU track (tests/golden/pipeline_c1_30s.npz)
+    float64 evaluation (tests/golden/pipeline_c1_30s_fp64.npz) = stand-in for exact arithmetic
+
+per pair: signed mean of the relative error and its standard error (lag-1-autocorrelation-corrected effective sample size), the running
+sum in cycles (10 ms per frame) -- end of chunk, largest excursion, and the excursion an unbiased random walk with the measured
+per-frame variance and autocorrelation would make --, and how the waveform distance follows the accumulated phase difference over time
+(per 100 ms window: relative waveform error against |phase difference|).  GPU box:
+
+    python tools/c1_f0_bias.py --out profiles/r05_c1_f0_bias.json [--tracks profiles/r05_c1_f0_tracks.npz]
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+
+
+def pair_stats(a, b, name):
+    """f0 track a against track b (Hz per 10 ms frame): signed statistics of what the source integrates."""
+    n = min(len(a), len(b))
+    a, b = a[:n], b[:n]
+    v = (a > 0) & (b > 0)
+    r = a[v] / b[v] - 1                                    # relative error, voiced frames
+    dhz = np.where(v, a - b, 0.0)                          # Hz; unvoiced frames contribute no phase
+    drift = np.cumsum(dhz) * 0.01                          # cycles of the fundamental (10 ms per frame)
+    m, s = float(r.mean()), float(r.std(ddof=1))
+    rc = r - m
+    rho1 = float((rc[1:] * rc[:-1]).sum() / (rc * rc).sum())
+    # autocorrelation time from the first lags that stay positive (Sokal's window would need more frames than a 36 s chunk has)
+    acf = [1.0]
+    for lag in range(1, 200):
+        c = float((rc[lag:] * rc[:-lag]).sum() / (rc * rc).sum())
+        if c <= 0.05:
+            break
+        acf.append(c)
+    tau = 1.0 + 2.0 * sum(acf[1:])                         # integrated autocorrelation time (frames)
+    n_eff = len(r) / tau
+    se = s / np.sqrt(n_eff)
+    # an UNBIASED walk with this per-frame spread and correlation: rms end-point = sigma_hz * 0.01 * sqrt(n * tau)
+    sig_hz = float(dhz[v].std(ddof=1))
+    walk_rms_end = sig_hz * 0.01 * np.sqrt(v.sum() * tau)
+    bias_end = float(dhz[v].mean()) * 0.01 * v.sum()       # what the signed mean alone integrates to
+    return {"pair": name, "voiced_frames": int(v.sum()), "voicing_flips": int(((a > 0) != (b > 0)).sum()),
+            "rel_rms": float(np.sqrt((r ** 2).mean())), "rel_max": float(np.abs(r).max()),
+            "rel_mean_signed": m, "rel_mean_standard_error": float(se), "mean_over_standard_error": float(m / se),
+            "lag1_autocorrelation": rho1, "autocorrelation_time_frames": float(tau), "effective_samples": float(n_eff),
+            "phase_end_of_chunk_cycles": float(drift[-1]), "phase_max_excursion_cycles": float(np.abs(drift).max()),
+            "phase_from_signed_mean_alone_cycles": bias_end,
+            "phase_rms_endpoint_of_an_unbiased_walk_cycles": float(walk_rms_end),
+            "verdict": ("bias" if abs(m / se) > 3 else "consistent with zero-mean correlated noise (|mean| < 3 standard errors)")}, drift
+
+
+def follow(out, ref, drift, sr_frames=400, win=10):
+    """Does the waveform distance follow the accumulated phase difference?  Per window of `win` frames: relative RMS waveform error
+    against the mean |phase difference| (cycles) -> Pearson correlation and the least-squares slope through the origin."""
+    n = min(len(out), len(ref)) // (sr_frames * win)
+    e, p = [], []
+    for i in range(n):
+        s = slice(i * sr_frames * win, (i + 1) * sr_frames * win)
+        den = np.sqrt((ref[s].astype(np.float64) ** 2).mean())
+        if den < 50:       # silence
+            continue
+        e.append(np.sqrt(((out[s].astype(np.float64) - ref[s]) ** 2).mean()) / den)
+        # the output is cut t_pad_tgt samples in: frame index of the window in the padded track
+        f0 = 300 + i * win
+        p.append(np.abs(drift[f0:f0 + win]).mean())
+    e, p = np.array(e), np.array(p)
+    return {"windows": int(len(e)), "pearson_r": float(np.corrcoef(e, p)[0, 1]),
+            "slope_rel_error_per_cycle": float((e * p).sum() / (p * p).sum()),
+            "median_rel_error": float(np.median(e)), "median_abs_phase_cycles": float(np.median(p))}
+
+
+def main():
+    out_path = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else None
+    tracks_path = sys.argv[sys.argv.index("--tracks") + 1] if "--tracks" in sys.argv else None
+    import torch
+    import conftest
+    conftest._bind("hip")
+    from test_pipeline import build, noise_fn_for
+    from synthetic import weights
+    from synthetic.inputs import vocal_like
+    gold = np.load(os.path.join(ROOT, "tests/golden/pipeline_c1_30s.npz"))
+    g64 = np.load(os.path.join(ROOT, "tests/golden/pipeline_c1_30s_fp64.npz"))
+    seed, x = int(gold["seed"][0]), tuple(int(v) for v in gold["x"])
+    nets = weights.full_model_set(seed)
+    audio = vocal_like(float(gold["seconds"][0]), 16000, seed + 5)
+    vc, hub, net_g, tgt_sr = build(conftest.Dev("hip"), nets, x)
+    f0_hip = np.zeros(len(gold["f0"]))
+    seen = []
+
+    def capture(lo, hi, f0):
+        arr = f0.detach().cpu().numpy() if torch.is_tensor(f0) else np.asarray(f0)
+        m = min(hi, len(f0_hip)) - lo
+        f0_hip[lo:lo + m] = arr[:m]
+        seen.append((lo, hi))
+        return f0
+    vc._estimated_f0 = capture
+    out = vc.pipeline(hub, net_g, 0, audio, "x.wav", [0, 0, 0], 0, "rmvpe", "", 0.5, 1, 3, tgt_sr, 0, 0.25, "v2", 0.33, 128,
+                      noise_fn=noise_fn_for(nets))
+    res = {"schedule": "progressive" if vc.last_profile["f0_progressive"] else "one launch", "f0_ranges": len(seen),
+           "frames": int(len(f0_hip))}
+    drifts = {}
+    res["pairs"] = []
+    for name, a, b in (("hip - fp64", f0_hip, g64["f0"]), ("reference - fp64", gold["f0"], g64["f0"]), ("hip - reference", f0_hip, gold["f0"])):
+        st, drifts[name] = pair_stats(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64), name)
+        res["pairs"].append(st)
+    ref = gold["audio"]
+    d = np.abs(out.astype(np.int64) - ref.astype(np.int64))
+    res["waveform_hip_vs_reference"] = {"rel_rms": float(np.sqrt((d.astype(np.float64) ** 2).sum() / (ref.astype(np.float64) ** 2).sum())),
+                                        "max_lsb": int(d.max()), "le1": float((d <= 1).mean())}
+    res["waveform_follows_phase_hip_vs_reference"] = follow(out, ref, drifts["hip - reference"])
+    line = json.dumps(res)
+    print(line)
+    if out_path:
+        with open(out_path, "w") as f:
+            f.write(json.dumps(res, indent=1) + "\n")
+    if tracks_path:
+        np.savez_compressed(tracks_path, f0_hip=f0_hip, f0_reference=gold["f0"], f0_fp64=g64["f0"], audio_hip_decim8=out[::8])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,12 +1,13 @@
 """The LDS-DMA staged k-tap 1-D convolution (csrc/conv_g1k.h) against the producer / consumer kernels on the vocoder's ResBlock layers
 (one 66 s chunk at 40 kHz: 256 ch x 73 080, 128 x 730 800, 64 x 1 461 600; x + conv(lrelu(x))), ROUND-ROBIN per shape;
-aicg_conv_desc.gemm_tile: 1 = conv_ws3, 2 / 3 = the 128 x 256 / 64 x 256 tile of conv_g1k, 0 = the library's policy."""
+aicg_conv_desc.gemm_tile: 1 = conv_ws3, 12 / 13 = the 128 x 256 / 64 x 256 tile of conv_g1k (development library only:
+AICG_LIB=dev), 0 = the library's policy."""
 import os, sys, statistics, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from aicovergen_amd import _lib, ops  # noqa: E402
 dev = torch.device("cuda:0")
-NAMES = {1: "ws3", 0: "policy", 2: "128x256", 3: "64x256"}
-codes = [int(c) for c in (sys.argv[1] if len(sys.argv) > 1 else "1,2,3,0").split(",")]
+NAMES = {1: "ws3", 0: "policy", 12: "128x256", 13: "64x256"}
+codes = [int(c) for c in (sys.argv[1] if len(sys.argv) > 1 else "1,12,13,0").split(",")]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 for c, t in [(256, 73080), (128, 730800), (64, 1461600)]:
     for k, d in [(3, 1), (3, 5), (7, 1), (7, 5), (11, 1), (11, 5)]:
