@@ -122,7 +122,7 @@ def make_rmvpe(name, cfg, seconds, seed):
     print(name, hidden.shape, float((f0 > 0).mean()))
 
 
-def make_pipeline(name, seconds, seed, full=False, x=(1, 1, 1, 2), f0_rows=None, resample_sr=0):
+def make_pipeline(name, seconds, seed, full=False, x=(1, 1, 1, 2), f0_rows=None, resample_sr=0, audio_seed=None, decim=1):
     """`full`: the full-size model set (HuBERT-base, RMVPE, 40 kHz v2 synthesizer) -- BASELINE config C1 when
     `seconds` = 30 and x = main.py's (3, 10, 60, 65) preset; the reference's f0 / coarse bins are stored too.
     End to end: the reference's own VC.pipeline (src/vc_infer_pipeline.py) + its synthesizer + its RMVPE, with
@@ -199,7 +199,7 @@ def make_pipeline(name, seconds, seed, full=False, x=(1, 1, 1, 2), f0_rows=None,
         nz, ns = opipe.chunk_noise(ci, T, cfg[2], upp, 7)
         return nz if which == 0 else ns.unsqueeze(-1)
 
-    audio = vocal_like(seconds, 16000, seed + 5)
+    audio = vocal_like(seconds, 16000, (seed if audio_seed is None else audio_seed) + 5)
     f0_seen = {}
     orig_get_f0 = vc.get_f0
 
@@ -236,6 +236,9 @@ def make_pipeline(name, seconds, seed, full=False, x=(1, 1, 1, 2), f0_rows=None,
     if full:
         extra.update(coarse=f0_seen["coarse"].astype(np.int16), f0=f0_seen["f0"].astype(np.float64), x=np.array(x),
                      ref_cpu_seconds=np.array([time.time() - t0]), ref_threads=np.array([torch.get_num_threads()]))
+    if audio_seed is not None:   # the C1 noise study (tools/c1_f0_bias.py --seeds): other inputs through the same networks, waveform decimated
+        extra.update(audio_seed=np.array([audio_seed]), decim=np.array([decim]))
+        out = out[::decim]
     np.savez_compressed(os.path.join(OUT_DIR, name + ".npz"), seed=np.array([seed]), seconds=np.array([seconds]), audio=out, **extra)
     print(name, out.shape, out.dtype, int(np.abs(out).max()), "%.1f s" % (time.time() - t0))
 
@@ -301,6 +304,12 @@ if __name__ == "__main__":
         # BASELINE config C1: 30 s mono 16 kHz through the reference's own VC.pipeline on the CPU, full-size networks,
         # main.py's chunk preset (one 576 000-sample padded chunk)
         make_pipeline("pipeline_c1_30s", 30.0, 1234, full=True, x=(3, 10, 60, 65))
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "c1seeds":
+        # C1 on OTHER inputs (same seeded networks): independent samples of how far two equally accurate fp32 evaluations of this
+        # pipeline land from each other (the f0 -> source-phase random walk, profiles/r05_c1_f0_bias.json).  Waveform every 4th sample
+        for a_seed in (2001, 2002, 2003):
+            make_pipeline("pipeline_c1_30s_audio%d" % a_seed, 30.0, 1234, full=True, x=(3, 10, 60, 65), audio_seed=a_seed, decim=4)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "branches":
         # the two public arguments rvc_infer never uses (src/rvc.py:150) but VC.pipeline accepts: an f0 curve file and resample_sr
