@@ -4,6 +4,7 @@
 #include "conv_ws3w.h"
 #include "conv_w2d.h"
 #include "conv_g1.h"
+#include "conv_g1s.h"
 #ifdef AICG_DEV_SWITCHES
 #include "conv_g1k.h"
 #endif
@@ -275,6 +276,16 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
             }
             if (rc <= 0) return rc;
         }
+    }
+
+    // LDS-DMA staged STRIDE-2 k-tap 1-D convolution (conv_g1s.h: k = 2 / 3, no padding, 16-byte aligned rows on both sides): HuBERT's feature
+    // extractor.  aicg_conv_desc.gemm_tile: 0 the policy, 1 off, 2 / 3 force the 128 x 256 / 64 x 256 tile.  Policy: the 128-row tile (two
+    // workgroups per CU) once it offers two waves of workgroups to every CU, the 64-row tile (three per CU) below that.
+    if (d->gemm_tile != 1 && !p.wsplit && p.Cout_g > 32 && conv_g1s_applicable(p, pad_w_end)) {
+        const long w128 = (long)p.N * idiv_up(p.Cout_g, 128) * idiv_up(p.Wo, 256);
+        const bool big = d->gemm_tile == 2 || (d->gemm_tile != 3 && w128 >= 512 && p.Cout_g % 128 != 64);
+        const int rc = big ? run_g1s_128x256(p, (hipStream_t)stream) : run_g1s_64x256(p, (hipStream_t)stream);
+        if (rc <= 0) return rc;
     }
 
 #ifdef AICG_DEV_SWITCHES

@@ -41,11 +41,14 @@ __device__ __forceinline__ void g1_wait_pieces() {   // at most N of this wave's
 // Epilogue shared by conv_g1_kernel and conv_g1k_kernel.  Register r of tile (i, j): row m_wave0 + 32 i + 8 (r >> 2) + 4 half + (r & 3),
 // position pos + j (pos = the first of this lane's four consecutive positions; HW % 4 == 0: a quad is inside the map or outside).
 // y = [y +] out_scale * (act(acc + bias [+ res]) [+ res | * res]); SHUF: the k = s = 2 ConvTranspose2d scatter.
-template <int TM, bool SHUF>
+// RAGGED (conv_g1s.h): HW is any length -- the quad that straddles the end of the row stores its leading elements one by one.
+template <int TM, bool SHUF, bool RAGGED = false>
 __device__ __forceinline__ void g1_epilogue(const ConvArgs& p, f32x16 (&acc)[TM][4], int img, int m_wave0, int pos, int HW) {
+    static_assert(!(SHUF && RAGGED), "the pixel-shuffle scatter works on whole quads");
     const int lane = (int)(threadIdx.x & 63), half = lane >> 5;
     const bool pos_ok = pos < HW;                                     // (HW % 4 == 0: a quad is inside the map or outside; no early exit --
                                                                       //  every lane's bias register is a shuffle source)
+    const int nvalid = RAGGED ? (HW - pos < 4 ? HW - pos : 4) : 4;     // elements of this lane's quad inside the row
     // bias: the wave's rows are contiguous -- one coalesced load per 64 rows, every (tile, register) slot picks its value with a shuffle
     constexpr int NBR = (TM * 32 + 63) / 64;
     float breg[NBR];
@@ -101,6 +104,22 @@ __device__ __forceinline__ void g1_epilogue(const ConvArgs& p, f32x16 (&acc)[TM]
                     if (m >= p.Cout_g || !pos_ok) continue;
                     float v[4] = {acc[i][0][r] + bv, acc[i][1][r] + bv, acc[i][2][r] + bv, acc[i][3][r] + bv};
                     float4 rv = make_float4(0.f, 0.f, 0.f, 0.f), yv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if constexpr (RAGGED) {
+                        if (nvalid < 4) {   // the row's last, partial quad: element by element
+#pragma unroll
+                            for (int t = 0; t < 3; ++t) {
+                                if (t >= nvalid) break;
+                                float x = v[t];
+                                const float rr1 = p.res ? p.res[r_col + (long)m * p.r_sc + t] : 0.f;
+                                if (p.res_first) x += rr1;
+                                x = act_static<ACT>(x, p.act, p.act_slope);
+                                if (!p.res_first) x += rr1;
+                                float* dst1 = p.y + y_col + (long)m * p.y_sc + t;
+                                *dst1 = x * p.out_scale + (p.accumulate ? *dst1 : 0.f);
+                            }
+                            continue;
+                        }
+                    }
                     if (p.res) rv = *reinterpret_cast<const float4*>(p.res + r_col + (long)m * p.r_sc);
                     if (p.accumulate) yv = *reinterpret_cast<const float4*>(p.y + y_col + (long)m * p.y_sc);
                     const float rr[4] = {rv.x, rv.y, rv.z, rv.w}, yy[4] = {yv.x, yv.y, yv.z, yv.w};

@@ -49,6 +49,39 @@ __global__ void __launch_bounds__(256) col2im_kernel(Col2imArgs p) {
     }
 }
 
+// ---- col2im, one-dimensional layers: the vocoder's up-sampling stages (reference models.py:494-505: ConvTranspose1d k 16 / s 10, k 4 / s 2, ...)
+// The generic kernel above walks OUTPUT elements (two 64-bit divisions each, and for stride s only every s-th lane reads the same
+// row of `cols`).  Here a thread owns one INPUT position q of one channel and forms the s outputs s q - pad + r, r = 0 .. s - 1:
+//     out[s q + r - pad] = bias + sum_j cols[co K + r + s j][q - j]            (j = 0 .. ceil(K / s) - 1, taps r + s j < K)
+// -- every row of `cols` is read as one unit-stride stream, 32-bit index arithmetic, no division.  The s x 256 outputs of a workgroup
+// are contiguous in the output row: they pass through LDS and leave as one unit-stride stream too (together with the `add` operand).
+template <int S>
+__global__ void __launch_bounds__(256) col2im1d_kernel(Col2imArgs p, int J) {
+    HIP_DYNAMIC_SHARED(float, c2i_tile)                     // 256 * s floats
+    const int s = S > 0 ? S : p.sw;
+    const int co = blockIdx.y, n = blockIdx.z, tid = threadIdx.x;
+    const int q0 = blockIdx.x * 256, q = q0 + tid;
+    const float* cn = p.cols + ((long)n * p.Cout + co) * p.KW * (long)p.Wi;
+    const float b = p.bias ? p.bias[co] : 0.f;
+#pragma unroll 2
+    for (int r = 0; r < s; ++r) {
+        float acc = b;
+        for (int j = 0; j < J; ++j) {
+            const int kk = r + s * j, qi = q - j;
+            if (kk < p.KW && qi >= 0 && qi < p.Wi) acc += cn[(long)kk * p.Wi + qi];
+        }
+        c2i_tile[tid * s + r] = apply_act(acc, p.act, p.slope);
+    }
+    __syncthreads();
+    const long nbase = (long)s * q0 - p.pw;                 // output index of the tile's first element
+    float* orow = p.out + (long)n * p.o_sn + (long)co * p.o_sc;
+    const float* arow = p.add ? p.add + (long)n * p.a_sn + (long)co * p.a_sc : nullptr;
+    for (int i = tid; i < 256 * s; i += 256) {
+        const long no = nbase + i;
+        if (no >= 0 && no < p.Wo) orow[no] = c2i_tile[i] + (arow ? arow[no] : 0.f);
+    }
+}
+
 // ---- NSF sine source (reference models.py:320-370 SineGen.forward + :414-419 SourceModuleHnNSF) --------
 // harmonic_num = 0.  phase[n] = sum_{m<=n} rad[floor(m/upp)], rad = (f0/sr) mod 1; the reference's
 // cumsum_shift only removes integers from the running fp32 sum, so the phase is
@@ -217,6 +250,17 @@ extern "C" int aicg_col2im(const float* cols, const float* bias, const float* ad
     if (total == 0) return AICG_OK;
     Col2imArgs p{cols, bias, add, out, N, Cout, Hi, Wi, Ho, Wo, KH, KW, stride_h, stride_w, pad_h, pad_w, act, slope,
                  (long)o_sn, (long)o_sc, (long)o_sh, (long)a_sn, (long)a_sc, (long)a_sh};
+    if (Hi == 1 && Ho == 1 && KH == 1 && stride_h == 1 && pad_h == 0 && Cout <= 65535 && N <= 65535 && stride_w <= 32) {
+        // one-dimensional layer: the input-centric form.  Positions q = 0 .. ceil((Wo + pad) / s): the last output is s q + r - pad
+        const int J = (KW + stride_w - 1) / stride_w;
+        const long nq = ((long)Wo + pad_w + stride_w - 1) / stride_w + 1;
+        dim3 grid((unsigned)ldiv_up(nq, 256), (unsigned)Cout, (unsigned)N);
+        const size_t lds = (size_t)256 * stride_w * sizeof(float);
+        if (stride_w == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(col2im1d_kernel<2>), grid, dim3(256), lds, (hipStream_t)stream, p, J);
+        else if (stride_w == 10) hipLaunchKernelGGL(HIP_KERNEL_NAME(col2im1d_kernel<10>), grid, dim3(256), lds, (hipStream_t)stream, p, J);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(col2im1d_kernel<0>), grid, dim3(256), lds, (hipStream_t)stream, p, J);
+        return check_launch("col2im1d_kernel");
+    }
     hipLaunchKernelGGL(col2im_kernel, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, p);
     return check_launch("col2im_kernel");
 }

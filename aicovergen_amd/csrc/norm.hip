@@ -132,10 +132,10 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {
 // one workgroup per row (channel): mean, variance (two passes), then normalise + act
 __global__ void __launch_bounds__(256) rownorm_act_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float* __restrict__ out, long T,
-                                                          float eps, int act) {
+                                                          long ld, float eps, int act) {
     __shared__ float sh[4];
     const long row = blockIdx.x;
-    const float* xr = x + row * T;
+    const float* xr = x + row * ld;
     float s = 0.f;
     for (long t = threadIdx.x; t < T; t += 256) s += xr[t];
     const float mean = block_sum_256(s, sh) / (float)T;
@@ -147,7 +147,7 @@ __global__ void __launch_bounds__(256) rownorm_act_kernel(const float* __restric
     const float var = block_sum_256(v, sh) / (float)T;
     const float rstd = rsqrtf(var + eps);
     const float g = gamma ? gamma[row] : 1.f, b = beta ? beta[row] : 0.f;
-    float* orow = out + row * T;
+    float* orow = out + row * ld;
     for (long t = threadIdx.x; t < T; t += 256) orow[t] = apply_act((xr[t] - mean) * rstd * g + b, act, 0.f);
 }
 
@@ -158,7 +158,8 @@ __global__ void __launch_bounds__(256) rownorm_act_kernel(const float* __restric
 //       in (2) -- the segments, always in the same order: one read of x, deterministic, as accurate as the two-pass form;
 //   (2) rownorm_apply_kernel: merges the row's partials, then normalise + affine + activation as one float4 stream.
 // Rows start at arbitrary 4-byte offsets (T is odd): a row is cut into <= 3 head scalars, an aligned float4 body and <= 3 tail
-// scalars; x and out must share their alignment (checked by the host wrapper).
+// scalars; x and out must share their alignment (checked by the host wrapper).  `ld` = row stride of x AND out (T for contiguous maps;
+// a multiple of 4 when the caller keeps rows 16-byte aligned for the DMA-staged convolution behind, conv_g1s.h: then every head is 0).
 struct Moments { float n, mean, m2; };
 
 __device__ __forceinline__ Moments merge(Moments a, Moments b) {
@@ -169,9 +170,9 @@ __device__ __forceinline__ Moments merge(Moments a, Moments b) {
 }
 
 struct RowSplit { int head; long nb4; int tail; long q4; };   // q4 = float4 per segment
-__device__ __forceinline__ RowSplit row_split(long row, long T, int nseg) {
+__device__ __forceinline__ RowSplit row_split(long row, long T, long ld, int nseg) {
     RowSplit r;
-    r.head = (int)((4 - ((row * T) & 3)) & 3);
+    r.head = (int)((4 - ((row * ld) & 3)) & 3);
     if (r.head > T) r.head = (int)T;
     r.nb4 = (T - r.head) >> 2;
     r.tail = (int)((T - r.head) & 3);
@@ -181,12 +182,12 @@ __device__ __forceinline__ RowSplit row_split(long row, long T, int nseg) {
 
 constexpr int kRnV = 16;   // float4 per thread and segment
 
-__global__ void __launch_bounds__(256) rownorm_stats_kernel(const float* __restrict__ x, float* __restrict__ part, long T, int nseg) {
+__global__ void __launch_bounds__(256) rownorm_stats_kernel(const float* __restrict__ x, float* __restrict__ part, long T, long ld, int nseg) {
     __shared__ Moments sh[4];
     const long row = blockIdx.y;
     const int seg = blockIdx.x, tid = threadIdx.x;
-    const float* xr = x + row * T;
-    const RowSplit rs = row_split(row, T, nseg);
+    const float* xr = x + row * ld;
+    const RowSplit rs = row_split(row, T, ld, nseg);
     const long b0 = (long)seg * rs.q4, b1 = lmin(b0 + rs.q4, rs.nb4);
     const float4* body = reinterpret_cast<const float4*>(xr + rs.head);
     float4 v[kRnV];
@@ -239,7 +240,7 @@ __device__ __forceinline__ float rn_act(float v, int act) {
 template <int ACT>
 __global__ void __launch_bounds__(256) rownorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ part,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            float* __restrict__ out, long T, int nseg, float eps, int act) {
+                                                            float* __restrict__ out, long T, long ld, int nseg, float eps, int act) {
     const long row = blockIdx.y;
     const int seg = blockIdx.x, tid = threadIdx.x;
     Moments m{0.f, 0.f, 0.f};
@@ -250,9 +251,9 @@ __global__ void __launch_bounds__(256) rownorm_apply_kernel(const float* __restr
     const float rstd = rsqrtf(m.m2 / (float)T + eps);
     const float g = gamma ? gamma[row] : 1.f, b = beta ? beta[row] : 0.f;
     // (x - mean) * rstd * g + b, written as the one-kernel form does: same rounding sequence
-    const float* xr = x + row * T;
-    float* orow = out + row * T;
-    const RowSplit rs = row_split(row, T, nseg);
+    const float* xr = x + row * ld;
+    float* orow = out + row * ld;
+    const RowSplit rs = row_split(row, T, ld, nseg);
     auto f = [&](float v) { return rn_act<ACT>((v - m.mean) * rstd * g + b, act); };
     const long b0 = (long)seg * rs.q4, b1 = lmin(b0 + rs.q4, rs.nb4);
     const float4* body = reinterpret_cast<const float4*>(xr + rs.head);
@@ -309,28 +310,33 @@ extern "C" int aicg_rownorm_act_workspace_floats(int rows, int64_t T, int64_t* n
     return AICG_OK;
 }
 
-extern "C" int aicg_rownorm_act(const float* x, const float* gamma, const float* beta, float* out, int rows, int64_t T,
-                                float eps, int act, float* workspace, void* stream) {
+extern "C" int aicg_rownorm_act_ld(const float* x, const float* gamma, const float* beta, float* out, int rows, int64_t T, int64_t ld,
+                                   float eps, int act, float* workspace, void* stream) {
     if (!x || !out) return fail(AICG_E_ARG, "aicg_rownorm_act: null pointer");
-    if (rows < 0 || T < 1) return fail(AICG_E_SHAPE, "aicg_rownorm_act: bad shape");
+    if (rows < 0 || T < 1 || ld < T) return fail(AICG_E_SHAPE, "aicg_rownorm_act: bad shape (rows %d, T %ld, row stride %ld)", rows, (long)T, (long)ld);
     if (rows == 0) return AICG_OK;
     if (workspace && T >= 4096 && (((uintptr_t)x | (uintptr_t)out) & 15) == 0) {
         const int nseg = (int)ldiv_up(T, 4L * 256 * kRnV);
         dim3 grid((unsigned)nseg, (unsigned)rows);
         hipStream_t st = (hipStream_t)stream;
-        hipLaunchKernelGGL(rownorm_stats_kernel, grid, dim3(256), 0, st, x, workspace, (long)T, nseg);
+        hipLaunchKernelGGL(rownorm_stats_kernel, grid, dim3(256), 0, st, x, workspace, (long)T, (long)ld, nseg);
         if (act == AICG_ACT_GELU)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(rownorm_apply_kernel<AICG_ACT_GELU>), grid, dim3(256), 0, st, x, (const float*)workspace,
-                               gamma, beta, out, (long)T, nseg, eps, act);
+                               gamma, beta, out, (long)T, (long)ld, nseg, eps, act);
         else if (act == AICG_ACT_NONE)
             hipLaunchKernelGGL(HIP_KERNEL_NAME(rownorm_apply_kernel<AICG_ACT_NONE>), grid, dim3(256), 0, st, x, (const float*)workspace,
-                               gamma, beta, out, (long)T, nseg, eps, act);
+                               gamma, beta, out, (long)T, (long)ld, nseg, eps, act);
         else
             hipLaunchKernelGGL(HIP_KERNEL_NAME(rownorm_apply_kernel<-1>), grid, dim3(256), 0, st, x, (const float*)workspace, gamma,
-                               beta, out, (long)T, nseg, eps, act);
+                               beta, out, (long)T, (long)ld, nseg, eps, act);
         return check_launch("rownorm_apply_kernel");
     }
     hipLaunchKernelGGL(rownorm_act_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, out,
-                       (long)T, eps, act);
+                       (long)T, (long)ld, eps, act);
     return check_launch("rownorm_act_kernel");
+}
+
+extern "C" int aicg_rownorm_act(const float* x, const float* gamma, const float* beta, float* out, int rows, int64_t T,
+                                float eps, int act, float* workspace, void* stream) {
+    return aicg_rownorm_act_ld(x, gamma, beta, out, rows, T, T, eps, act, workspace, stream);
 }

@@ -142,19 +142,26 @@ class HubertModel:
         x = source.to(dev).float().contiguous()
         n = x.shape[1]
         cur = x.view(1, 1, n)
+
+        def rows16(c, t):
+            """(1, c, t) view of a buffer whose rows start on 16-byte boundaries (row stride rounded up to a multiple of four floats): the
+            extractor's frame counts are odd (211 231 -> 105 615 -> ...), and the stride-2 layers are staged by 16-byte DMA pieces
+            (csrc/conv_g1s.h).  The padding is never read into a stored result and never written."""
+            return torch.empty((1, c, (t + 3) // 4 * 4), dtype=torch.float32, device=dev)[:, :, :t]
+
         for i, (kind, s, pc) in enumerate(P["fe"]):
             act = ops.ACT_NONE if i == 0 else ops.ACT_GELU
             if kind == "phase":
                 to = (n - 2 * s) // s + 1
                 nq = (n + s - 1) // s
                 xp = torch.nn.functional.pad(cur.view(-1), (0, nq * s - n))          # zero fill to a multiple of s
-                cur = ops.conv(xp.view(nq, s).t().contiguous().unsqueeze(0), pc, act=act, out_len=to)
+                cur = ops.conv(xp.view(nq, s).t().contiguous().unsqueeze(0), pc, act=act, out_len=to, out=rows16(pc.cout, to))
             else:
-                cur = ops.conv(cur, pc, act=act)
+                cur = ops.conv(cur, pc, act=act, out=rows16(pc.cout, pc.out_hw(1, cur.shape[2])[1]))
             if i == 0:  # GroupNorm(C, C): per-channel statistics over the whole chunk, then GELU
                 cur = ops.rownorm_act(cur[0], P["gn_w"], P["gn_b"], act=ops.ACT_GELU).unsqueeze(0)
         T = cur.shape[2]
-        h = ops.layernorm_ct(cur, P["ln_w"], P["ln_b"])
+        h = ops.layernorm_ct(cur.contiguous(), P["ln_w"], P["ln_b"])   # (a copy of 512 x T only when T % 4 != 0)
         h = ops.conv(h, P["proj"])
         # x + GELU(SamePad(pos_conv(x))): the even kernel's extra last frame is simply not computed
         h = ops.conv(h, P["pos"], act=ops.ACT_GELU, res=h, out_len=T)

@@ -556,16 +556,19 @@ def layernorm_ct(x, gamma, beta, res=None, out=None, eps=1e-5):
 
 
 def rownorm_act(x, gamma, beta, act=ACT_NONE, eps=1e-5, out=None):
-    """x: (rows, T) contiguous: per-row (x - mean)/sqrt(var + eps) * gamma + beta, then act."""
-    assert x.is_contiguous() and x.dim() == 2
+    """x: (rows, T), unit stride along T: per-row (x - mean)/sqrt(var + eps) * gamma + beta, then act.  x (and out) may be views of rows
+    padded to a common stride (x.stride(0) >= T); `out` defaults to a buffer laid out like x."""
+    assert x.dim() == 2 and (x.stride(1) == 1 or x.shape[1] == 1)
+    rows, t = x.shape
+    ld = x.stride(0) if rows > 1 else max(x.stride(0), t)
     if out is None:
-        out = torch.empty_like(x)
+        out = torch.empty((rows, ld), dtype=torch.float32, device=x.device)[:, :t] if ld != t else torch.empty_like(x)
+    assert out.shape == x.shape and (out.stride(1) == 1 or t == 1) and (rows <= 1 or out.stride(0) == ld)
     _check(x, gamma, beta, out)
     need = ctypes.c_int64(0)
-    _call("aicg_rownorm_act_workspace_floats", x.shape[0], x.shape[1], ctypes.addressof(need))
+    _call("aicg_rownorm_act_workspace_floats", rows, t, ctypes.addressof(need))
     ws = torch.empty(need.value, dtype=torch.float32, device=x.device) if need.value else None
-    _call("aicg_rownorm_act", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), x.shape[0], x.shape[1], float(eps), act, _ptr(ws),
-              _stream(x))
+    _call("aicg_rownorm_act_ld", _ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), rows, t, ld, float(eps), act, _ptr(ws), _stream(x))
     return out
 
 

@@ -188,6 +188,10 @@ int aicg_layernorm_ct(const float* x, const float* res, const float* gamma, cons
 int aicg_rownorm_act_workspace_floats(int rows, int64_t T, int64_t* n_floats);
 int aicg_rownorm_act(const float* x, const float* gamma, const float* beta, float* out, int rows, int64_t T,
                      float eps, int act, float* workspace, void* stream);
+/* ... with a row stride `ld` >= T shared by x and out (ABI 4): the extractor keeps its activations in rows padded to a multiple of four
+ * floats so that the stride-2 layers behind can be staged by 16-byte DMA (csrc/conv_g1s.h); the padding is neither read nor written */
+int aicg_rownorm_act_ld(const float* x, const float* gamma, const float* beta, float* out, int rows, int64_t T, int64_t ld,
+                        float eps, int act, float* workspace, void* stream);
 
 /* Fused softmax attention over channel-major q/k/v (H*D, T): o = softmax(scale * q^T k + relk) v.
  * relk (H, 2*window+1, T) holds q_i . E^k_m (attentions.py:238-243) or is NULL (HuBERT).  lse (H, T) receives the

@@ -307,9 +307,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "c1seeds":
         # C1 on OTHER inputs (same seeded networks): independent samples of how far two equally accurate fp32 evaluations of this
-        # pipeline land from each other (the f0 -> source-phase random walk, profiles/r05_c1_f0_bias.json).  Waveform every 4th sample
-        for a_seed in (2001, 2002, 2003):
-            make_pipeline("pipeline_c1_30s_audio%d" % a_seed, 30.0, 1234, full=True, x=(3, 10, 60, 65), audio_seed=a_seed, decim=4)
+        # pipeline land from each other (the f0 -> source-phase random walk, profiles/r05_c1_f0_bias.json).  Waveform every 16th sample
+        for a_seed in range(2001, 2009):
+            make_pipeline("pipeline_c1_30s_audio%d" % a_seed, 30.0, 1234, full=True, x=(3, 10, 60, 65), audio_seed=a_seed, decim=16)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "branches":
         # the two public arguments rvc_infer never uses (src/rvc.py:150) but VC.pipeline accepts: an f0 curve file and resample_sr

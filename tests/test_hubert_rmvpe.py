@@ -34,6 +34,35 @@ def test_hubert_tiny_matches_oracle(dev):
         assert rel_rms(y1, ohub.extract_features(sd, cfg, wav, 1)) < 1e-4
 
 
+def test_hubert_extractor_on_the_stride2_dma_kernel(dev):
+    """A 64-channel extractor: wide enough for csrc/conv_g1s.h, so the five stride-2 layers behind layer 0 run the DMA-staged kernel on
+    rows padded to 16 bytes (frame counts 1 999 -> 999 -> 499 -> ...: every residue mod 4) -- against the oracle, and the routing is
+    asserted (HUBERT_TINY's 32 channels stay on the producer / consumer kernels)."""
+    from aicovergen_amd import _lib
+    cfg = dict(weights.HUBERT_TINY, conv_dim=64)
+    sd = weights.hubert_state_dict(cfg, 4321)
+    m = HubertModel(sd, cfg).to(dev.device)
+    torch.manual_seed(1)
+    wav = torch.randn(1, 10003) * 0.3
+    seen = []
+    orig = ops.conv
+
+    def spy(x, pc, *a, **k):
+        y = orig(x, pc, *a, **k)
+        if pc.stride[1] == 2:
+            seen.append(_lib.last_launch())
+        return y
+    ops.conv = spy
+    try:
+        y, _ = m.extract_features(source=wav, padding_mask=None, output_layer=12)
+    finally:
+        ops.conv = orig
+    assert seen == ["conv_g1s_kernel"] * 6, seen
+    with torch.no_grad():
+        ref = ohub.extract_features(sd, cfg, wav, 12)
+    assert y.shape == ref.shape and rel_rms(y, ref) < 1e-4
+
+
 def test_hubert_many_chunks_at_once(dev):
     """extract_features_many: the transformer's per-token layers run once over chunks of different lengths laid side by side;
     every chunk must come out as from its own call (other GEMM tiles: fp32 summation order only) and match the oracle."""

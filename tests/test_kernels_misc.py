@@ -26,6 +26,28 @@ def test_conv_transpose1d(dev, ci, co, k, s, T):
     assert rel_rms(y, ref) < 1e-5
 
 
+@pytest.mark.parametrize("n,ci,co,k,s,pad,opad,T", [(1, 16, 8, 4, 2, 1, 0, 300), (2, 16, 5, 16, 10, 3, 0, 257), (1, 16, 8, 5, 3, 1, 1, 513),
+                                                    (1, 16, 8, 3, 2, 0, 1, 256), (3, 16, 4, 7, 1, 3, 0, 130), (1, 16, 8, 2, 4, 0, 0, 65)])
+def test_conv_transpose1d_col2im_forms(dev, n, ci, co, k, s, pad, opad, T):
+    """The input-centric 1-D col2im (csrc/elementwise.hip col2im1d_kernel): tiles of 256 input positions (several, with a tail), batches,
+    kernels that are not a multiple of the stride, stride 1, stride > kernel (outputs that only see the bias), padding and
+    output_padding, an activation in front of the `add` operand, an output written into a channel slice."""
+    torch.manual_seed(k * 100 + s)
+    x = torch.randn(n, ci, T)
+    w = torch.randn(ci, co, k) * 0.1
+    b = torch.randn(co)
+    pt = ops.PackedConvTranspose(w, b, stride=s, padding=pad, output_padding=opad, device=dev.device)
+    L = pt.out_hw(1, T)[1]
+    ref = F.conv_transpose1d(x, w, b, stride=s, padding=pad, output_padding=opad)
+    assert ref.shape[2] == L
+    add = torch.randn(n, co, L)
+    buf = dev.t(torch.full((n, co + 2, L), 3.0))
+    y = ops.conv_transpose(dev.t(x), pt, add=dev.t(add), act=ops.ACT_LRELU, act_slope=0.2, out=buf[:, 1:1 + co])
+    assert rel_rms(y, F.leaky_relu(ref, 0.2) + add) < 1e-5
+    assert bool((buf[:, 0] == 3.0).all()) and bool((buf[:, -1] == 3.0).all())
+    assert rel_rms(ops.conv_transpose(dev.t(x), pt), ref) < 1e-5
+
+
 def test_conv_transpose2d(dev):
     """rmvpe.ResDecoderBlock.conv1 (rmvpe.py:147-155): 3x3 stride 2 pad 1 output_padding 1; MDX 2x2 stride 2."""
     torch.manual_seed(2)

@@ -14,7 +14,13 @@ sum in cycles (10 ms per frame) -- end of chunk, largest excursion, and the excu
 per-frame variance and autocorrelation would make --, and how the waveform distance follows the accumulated phase difference over time
 (per 100 ms window: relative waveform error against |phase difference|).  GPU box:
 
-    python tools/c1_f0_bias.py --out profiles/r05_c1_f0_bias.json [--tracks profiles/r05_c1_f0_tracks.npz]
+    python tools/c1_f0_bias.py --out profiles/r05_c1_f0_bias.json [--tracks profiles/r05_c1_f0_tracks.npz] [--samples]
+
+--samples adds INDEPENDENT samples of the same quantity (how far two equally accurate fp32 evaluations land from each other):
+the C1 input under other, equally valid HIP summation orders (single-workgroup GRU; one-launch schedule), and eight other inputs through
+the same networks against the reference's own run on them (tests/golden/pipeline_c1_30s_audio2001..2008.npz, make_golden.py c1seeds);
+and a Monte-Carlo of the noise model -- unbiased white per-frame f0 error of the measured spread, waveform error = slope x |phase
+difference| as measured -- that turns the spread into quantiles of the waveform distance: the test's gate is read off it.
 """
 import json
 import os
@@ -82,6 +88,19 @@ def follow(out, ref, drift, sr_frames=400, win=10):
             "median_rel_error": float(np.median(e)), "median_abs_phase_cycles": float(np.median(p))}
 
 
+def monte_carlo(sig_hz, slope, frames, trials=20000, seed=0):
+    """Waveform relative RMS between two evaluations whose f0 differs by unbiased white noise of `sig_hz` per frame: the phase
+    difference is a random walk (10 ms per frame), the waveform error follows it with `slope` (relative error per cycle)."""
+    rng = np.random.default_rng(seed)
+    q = []
+    for i in range(0, trials, 2000):
+        w = np.cumsum(rng.normal(0.0, sig_hz * 0.01, size=(2000, frames)), axis=1)
+        q.append(slope * np.sqrt((w ** 2).mean(axis=1)))
+    q = np.concatenate(q)
+    return {"median": float(np.median(q)), "p90": float(np.quantile(q, 0.9)), "p95": float(np.quantile(q, 0.95)),
+            "p99": float(np.quantile(q, 0.99)), "p999": float(np.quantile(q, 0.999)), "mean": float(q.mean())}, q
+
+
 def main():
     out_path = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else None
     tracks_path = sys.argv[sys.argv.index("--tracks") + 1] if "--tracks" in sys.argv else None
@@ -120,7 +139,77 @@ def main():
     d = np.abs(out.astype(np.int64) - ref.astype(np.int64))
     res["waveform_hip_vs_reference"] = {"rel_rms": float(np.sqrt((d.astype(np.float64) ** 2).sum() / (ref.astype(np.float64) ** 2).sum())),
                                         "max_lsb": int(d.max()), "le1": float((d <= 1).mean())}
-    res["waveform_follows_phase_hip_vs_reference"] = follow(out, ref, drifts["hip - reference"])
+    fol = follow(out, ref, drifts["hip - reference"])
+    res["waveform_follows_phase_hip_vs_reference"] = fol
+    # ---- the noise model and what it says about the distances observed
+    slope = fol["slope_rel_error_per_cycle"]
+    n = len(f0_hip)
+    sig = {p["pair"]: float(np.std(np.asarray(a, dtype=np.float64)[:n] - np.asarray(b, dtype=np.float64)[:n], ddof=1))
+           for p, (a, b) in zip(res["pairs"], ((f0_hip, g64["f0"]), (gold["f0"], g64["f0"]), (f0_hip, gold["f0"])))}
+    model = {}
+    for name, observed in (("hip - reference", res["waveform_hip_vs_reference"]["rel_rms"]),
+                           ("reference - fp64", float(g64["ref_rel_rms"][0]))):
+        qs, q = monte_carlo(sig[name], slope, n)
+        model[name] = {"f0_sigma_hz_per_frame": sig[name], "waveform_rel_rms_quantiles": qs, "observed": observed,
+                       "observed_percentile": float((q < observed).mean())}
+    res["noise_model"] = model
+    if "--samples" in sys.argv:
+        from aicovergen_amd import ops
+
+        def distance(o, r, decim=1):
+            d = np.abs(o[::decim].astype(np.int64) - r.astype(np.int64))
+            return {"rel_rms": float(np.sqrt((d.astype(np.float64) ** 2).sum() / (r.astype(np.float64) ** 2).sum())),
+                    "max_lsb": int(d.max()), "le1": float((d <= 1).mean())}
+
+        def run(aud, **env):
+            old = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            try:
+                cap = np.zeros(n)
+
+                def capture2(lo, hi, f0):
+                    arr = f0.detach().cpu().numpy() if torch.is_tensor(f0) else np.asarray(f0)
+                    m = min(hi, n) - lo
+                    cap[lo:lo + m] = arr[:m]
+                    return f0
+                vc._estimated_f0 = capture2
+                o = vc.pipeline(hub, net_g, 0, aud, "x.wav", [0, 0, 0], 0, "rmvpe", "", 0.5, 1, 3, tgt_sr, 0, 0.25, "v2", 0.33, 128,
+                                noise_fn=noise_fn_for(nets))
+                return o, cap
+            finally:
+                for k, v in old.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+        samples = []
+        # (a) the C1 input under other equally valid summation orders of the f0 path
+        o1, f1 = run(audio, AICG_F0_SEGMENTS="1")
+        samples.append(dict(sample="C1 input, one-launch schedule (classifier GEMM over the whole track)", **distance(o1, ref),
+                            phase_end_vs_reference_cycles=float(np.sum(f1 - gold["f0"][:n]) * 0.01)))
+        old2 = ops.GRU_TWO_WORKGROUPS
+        ops.GRU_TWO_WORKGROUPS = False
+        try:
+            o2, f2 = run(audio)
+        finally:
+            ops.GRU_TWO_WORKGROUPS = old2
+        samples.append(dict(sample="C1 input, single-workgroup GRU kernel (another summation order of the recurrence)", **distance(o2, ref),
+                            phase_end_vs_reference_cycles=float(np.sum(f2 - gold["f0"][:n]) * 0.01)))
+        # (b) other inputs through the same networks, against the reference's own run on them
+        for a_seed in range(2001, 2009):
+            path = os.path.join(ROOT, "tests/golden/pipeline_c1_30s_audio%d.npz" % a_seed)
+            if not os.path.exists(path):
+                continue
+            g = np.load(path)
+            aud = vocal_like(float(g["seconds"][0]), 16000, a_seed + 5)
+            o, f = run(aud)
+            m = min(n, len(g["f0"]))
+            dhz = f[:m] - g["f0"][:m]
+            samples.append(dict(sample="input seed %d vs the reference's run on it" % a_seed, **distance(o, g["audio"], int(g["decim"][0])),
+                                f0_rel_rms=float(np.sqrt(np.mean((f[:m] / g["f0"][:m] - 1) ** 2))),
+                                f0_sigma_hz=float(dhz.std(ddof=1)), phase_end_vs_reference_cycles=float(dhz.sum() * 0.01),
+                                coarse_bins_differ=None))
+        res["independent_samples"] = samples
     line = json.dumps(res)
     print(line)
     if out_path:
