@@ -5,6 +5,7 @@
 #include "conv_w2d.h"
 #include "conv_g1.h"
 #include "conv_g1s.h"
+#include "conv_g1w.h"
 #ifdef AICG_DEV_SWITCHES
 #include "conv_g1k.h"
 #endif
@@ -151,6 +152,24 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
     p.w3 = d->packed_v3 ? w_packed + (long)p.groups * p.w_group_stride : nullptr;
     p.wsplit = d->packed_v3 && d->split ? w_packed + 2L * p.groups * p.w_group_stride : nullptr;
 
+    if (d->wino == 8) {
+        // one-dimensional Winograd F(2, 3) of a k = 3 / 7 / 11, dilation-1 layer (conv_g1w.h): w_packed is the image pair of the
+        // (Cout, Cin, 1, S) slot kernel, S = 4 / 10 / 15 (ops.winograd1d_kernel)
+        if (!d->packed_v3 || (p.KW != 3 && p.KW != 7 && p.KW != 11))
+            return fail(AICG_E_ARG, "aicg_conv_forward: wino 8 needs a packed k = 3 / 7 / 11 one-dimensional layer");
+        const int nslot = p.KW == 3 ? 4 : p.KW == 7 ? 10 : 15;
+        p.w3 = w_packed + (long)nslot * p.Cin_pad * p.Mpad;
+        if (!conv_g1w_applicable(p, pad_w_end))
+            return fail(AICG_E_ARG, "aicg_conv_forward: wino 8 needs stride 1, dilation 1, same padding, one group, W %% 4 == 0, 16-byte aligned "
+                                    "rows (strides %% 4 == 0), no input activation but a leaky ReLU");
+        hipStream_t st8 = (hipStream_t)stream;
+        // aicg_conv_desc.gemm_tile 2 / 3 / 4 force the 64 x 256 / 32 x 512 / 128 x 128 tile (tools); policy: 32-row layers on the 32 x 512
+        // tile (all four waves share the rows), everything else on 64 x 256
+        const int rc = d->gemm_tile == 3 ? run_g1w_32x512(p, st8) : d->gemm_tile == 4 ? run_g1w_128x128(p, st8) :
+                       d->gemm_tile == 2 ? run_g1w_64x256(p, st8) : p.Cout_g <= 32 ? run_g1w_32x512(p, st8) : run_g1w_64x256(p, st8);
+        if (rc == 1) return fail(AICG_E_SHAPE, "aicg_conv_forward: wino 8 layer does not fit the kernel's LDS budget");
+        return rc;
+    }
     if (d->wino) {
         // Winograd F(2, 3) along rows (conv_ws3w.h): w_packed is the image pair of the (Cout, Cin, 3, 4) kernel, 12 taps;
         // wino == 2: F(2 x 2, 3 x 3) (conv_w2d.h): w_packed is the [Cout / 48][Cin / 8][2][16][4][48] image of U = G g G^T
@@ -279,12 +298,16 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
     }
 
     // LDS-DMA staged STRIDE-2 k-tap 1-D convolution (conv_g1s.h: k = 2 / 3, no padding, 16-byte aligned rows on both sides): HuBERT's feature
-    // extractor.  aicg_conv_desc.gemm_tile: 0 the policy, 1 off, 2 / 3 force the 128 x 256 / 64 x 256 tile.  Policy: the 128-row tile (two
-    // workgroups per CU) once it offers two waves of workgroups to every CU, the 64-row tile (three per CU) below that.
+    // extractor.  aicg_conv_desc.gemm_tile: 0 the policy, 1 off, 2 / 3 force the 128 x 256 / 64 x 256 tile.  Policy, measured round-robin
+    // on the extractor's six layers (tools/kbench_g1s.py, profiles/r05_kbench_g1s.txt): the 64-row tile (three workgroups per CU) wins on
+    // every layer -- 138.6 / 128.1 / 108.2 / 106.2 TFLOP/s on the k = 3 layers against 128.6 / 111.6 / 107.9 / 103.5 for the 128-row tile and
+    // 111.3 / 103.0 / 92.5 / 78.2 for conv_ws3 -- down to ~200 workgroups (k = 2 on 13 201 frames: 83 us against 99); the last layer
+    // (104 workgroups) stays on conv_ws3's smaller tiles (55 us against 83).
     if (d->gemm_tile != 1 && !p.wsplit && p.Cout_g > 32 && conv_g1s_applicable(p, pad_w_end)) {
-        const long w128 = (long)p.N * idiv_up(p.Cout_g, 128) * idiv_up(p.Wo, 256);
-        const bool big = d->gemm_tile == 2 || (d->gemm_tile != 3 && w128 >= 512 && p.Cout_g % 128 != 64);
-        const int rc = big ? run_g1s_128x256(p, (hipStream_t)stream) : run_g1s_64x256(p, (hipStream_t)stream);
+        const long w64 = (long)p.N * idiv_up(p.Cout_g, 64) * idiv_up(p.Wo, 256);
+        int rc = 1;
+        if (d->gemm_tile == 2) rc = run_g1s_128x256(p, (hipStream_t)stream);
+        else if (d->gemm_tile == 3 || w64 >= 160) rc = run_g1s_64x256(p, (hipStream_t)stream);
         if (rc <= 0) return rc;
     }
 

@@ -254,6 +254,33 @@ def winograd2d_image(w, quads=False):
     return Up.view(co // 48, 48, cpad // 8, 2, 4, 16).permute(0, 2, 3, 5, 4, 1).contiguous().view(-1)
 
 
+# One-dimensional Winograd F(2, 3) for the vocoder's k = 3 / 7 / 11 ResBlock layers of dilation 1 (csrc/conv_g1w.h): 4 / 10 / 15 products
+# per output pair and input channel instead of 6 / 14 / 22.  Layers packed while this is set carry the slot image next to the direct one;
+# conv() takes it where the kernel applies (aligned rows, W % 4 == 0, enough positions).  The f0 models never do (fp32_layers()).
+winograd1d = os.environ.get("AICG_WINOGRAD1D", "1") != "0"
+winograd1d_min_positions = 16384
+
+
+def winograd1d_kernel(w):
+    """(Cout, Cin, K), K in {3, 7, 11} -> (Cout, Cin, S) slot weights of csrc/conv_g1w.h, S = 4 / 10 / 15: per 3-tap group (g0, g1, g2)
+    the four F(2, 3) weights (g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2); a remainder of two taps (a, b): (a, a + b, b); one tap a:
+    (a, -a).  Sums in float64, rounded once."""
+    k = w.shape[-1]
+    assert k in (3, 7, 11)
+    wd = w.detach().double()
+    slots = []
+    for g in range(k // 3):
+        g0, g1, g2 = wd[..., 3 * g], wd[..., 3 * g + 1], wd[..., 3 * g + 2]
+        slots += [g0, (g0 + g1 + g2) * 0.5, (g0 - g1 + g2) * 0.5, g2]
+    if k % 3 == 2:
+        a, b = wd[..., k - 2], wd[..., k - 1]
+        slots += [a, a + b, b]
+    elif k % 3 == 1:
+        a = wd[..., k - 1]
+        slots += [a, -a]
+    return torch.stack(slots, -1).to(torch.float32).contiguous()
+
+
 class PackedConv:
     """A convolution layer ready for aicg_conv_forward: packed weights + geometry.  1-D layers use KH=1."""
 
@@ -275,7 +302,11 @@ class PackedConv:
         self.split = bool(split_precision)
         self.w = pack_conv_weight(weight.to(device), groups, self.split)
         self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
-        self.w_wino = self.w_wino2 = self.w_wino2q = None
+        self.w_wino = self.w_wino2 = self.w_wino2q = self.w_wino1 = None
+        if (winograd1d and not self.split and not _fp32_depth and self.kh == 1 and self.kw in (3, 7, 11) and stride == (1, 1)
+                and dilation == (1, 1) and padding == (0, (self.kw - 1) // 2) and self.padding_end is None and groups == 1 and cin_g >= 16):
+            # slot image of the 1-D Winograd form, packed like any k-tap kernel (slots in the taps' place)
+            self.w_wino1 = pack_conv_weight(winograd1d_kernel(weight.detach().to(device=device, dtype=torch.float32)[:, :, 0]).unsqueeze(2), 1, False)
         if (winograd and not self.split and not _fp32_depth and (self.kh, self.kw) == (3, 3) and stride == (1, 1) and dilation == (1, 1)
                 and padding == (1, 1) and self.padding_end is None and groups == 1 and cin_g >= 8):
             self.w_wino = pack_conv_weight(winograd_kernel(weight.detach().to(device=device, dtype=torch.float32)), 1, False)
@@ -405,14 +436,20 @@ def conv(x, pc, res=None, out=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NON
     # ... its two-dimensional form where the layer has it and the map is float4-aligned
     wino2 = (wino and winograd2d and getattr(pc, "w_wino2", None) is not None and w % 4 == 0 and x4.stride(0) % 4 == 0 and x4.stride(1) % 4 == 0
              and x4.stride(2) % 4 == 0 and x4.data_ptr() % 16 == 0)
+    # the one-dimensional form F(2, 3) of a k = 3 / 7 / 11 layer (csrc/conv_g1w.h): aligned rows of a multiple of four positions
+    wino1 = (winograd1d and getattr(pc, "w_wino1", None) is not None and is1d and not shuffle and out_len is None and w % 4 == 0
+             and n * w >= winograd1d_min_positions and pre_act in (ACT_NONE, ACT_LRELU) and 0.0 <= pre_slope <= 1.0
+             and x4.data_ptr() % 16 == 0 and x4.stride(0) % 4 == 0 and x4.stride(1) % 4 == 0 and x4.stride(1) >= w
+             and o4.data_ptr() % 16 == 0 and o4.stride(0) % 4 == 0 and o4.stride(1) % 4 == 0
+             and (r4 is None or (r4.data_ptr() % 16 == 0 and r4.stride(0) % 4 == 0 and r4.stride(1) % 4 == 0)))
     # 2 / 3: eight / four waves per workgroup; + 2: quad fragments
     d.gemm_tile = gemm_tile
-    d.wino = (winograd2d_code or (2 if winograd2d_waves == 8 else 3) + (2 if winograd2d_quads else 0)) if wino2 else 1 if wino else 0
+    d.wino = (winograd2d_code or (2 if winograd2d_waves == 8 else 3) + (2 if winograd2d_quads else 0)) if wino2 else 1 if wino else 8 if wino1 else 0
     prof = conv_profile
     if prof is not None and x.is_cuda:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _call("aicg_conv_forward", ctypes.addressof(d), _ptr(x4), _ptr((pc.wino2q() if winograd2d_quads else pc.w_wino2) if wino2 else pc.w_wino if wino else pc.w), _ptr(b), _ptr(r4), _ptr(o4), _stream(x))
+    _call("aicg_conv_forward", ctypes.addressof(d), _ptr(x4), _ptr((pc.wino2q() if winograd2d_quads else pc.w_wino2) if wino2 else pc.w_wino if wino else pc.w_wino1 if wino1 else pc.w), _ptr(b), _ptr(r4), _ptr(o4), _stream(x))
     if prof is not None and x.is_cuda:
         e1.record()
         prof.events.append((e0, e1))

@@ -130,7 +130,13 @@ typedef struct aicg_conv_desc {
                                      2 x 2 output block) of the same kind of layer; w_packed is ONE image,
                                      [Cout / 48][ceil(Cin / 8)][s = 0..1][point p = 4 i + q][ks = 0..3][m = 0..47] floats with element
                                      U[48 mu + m][8 chunk + 4 s + ks][i][q], U = G g G^T, G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]
-                                     (zero beyond Cin).  Needs Cout % 48 == 0, W % 4 == 0, x 16-byte aligned with strides % 4 == 0 */
+                                     (zero beyond Cin).  Needs Cout % 48 == 0, W % 4 == 0, x 16-byte aligned with strides % 4 == 0.
+                                     8: the ONE-dimensional form F(2, 3) of a k = 3 / 7 / 11, stride 1, dilation 1, "same"-padded 1-D layer
+                                     (csrc/conv_g1w.h: 4 / 10 / 15 instead of 6 / 14 / 22 contractions per output pair -- the vocoder's
+                                     ResBlocks, src/infer_pack/modules.py:299-312); w_packed holds the packed images of the
+                                     (Cout, Cin, 1, S) SLOT kernel: per 3-tap group (g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2), a
+                                     remainder of two taps (a, a + b, b), of one tap (a, -a).  Residual / accumulate / out_scale and a
+                                     leaky-ReLU input activation are supported; needs W % 4 == 0 and 16-byte aligned rows of x, y, res */
     int32_t gemm_tile;            /* 1 x 1 layers the LDS-DMA staged GEMM can take (csrc/conv_g1.h: unit stride, no padding, one group, no
                                      input activation but a leaky ReLU, contiguous 16-byte-aligned maps of a multiple of 4 positions): 0 the library's
                                      policy; 1 never that kernel; 2 / 3 / 4 its 128 x 256 / 64 x 256 / 192 x 256 tile (rows x positions

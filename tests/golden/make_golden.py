@@ -308,8 +308,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "c1seeds":
         # C1 on OTHER inputs (same seeded networks): independent samples of how far two equally accurate fp32 evaluations of this
         # pipeline land from each other (the f0 -> source-phase random walk, profiles/r05_c1_f0_bias.json).  Waveform every 16th sample
-        for a_seed in range(2001, 2009):
-            make_pipeline("pipeline_c1_30s_audio%d" % a_seed, 30.0, 1234, full=True, x=(3, 10, 60, 65), audio_seed=a_seed, decim=16)
+        first, last = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (2001, 2008)
+        for a_seed in range(first, last + 1):
+            make_pipeline("pipeline_c1_30s_audio%d" % a_seed, 30.0, 1234, full=True, x=(3, 10, 60, 65), audio_seed=a_seed,
+                          decim=16 if a_seed <= 2008 else 64)
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "branches":
         # the two public arguments rvc_infer never uses (src/rvc.py:150) but VC.pipeline accepts: an f0 curve file and resample_sr

@@ -53,10 +53,12 @@ def test_hubert_extractor_on_the_stride2_dma_kernel(dev):
             seen.append(_lib.last_launch())
         return y
     ops.conv = spy
+    ops.gemm_tile = 3       # (the policy keeps launches of fewer than 160 workgroups on the producer / consumer kernels: force the tile)
     try:
         y, _ = m.extract_features(source=wav, padding_mask=None, output_layer=12)
     finally:
         ops.conv = orig
+        ops.gemm_tile = 0
     assert seen == ["conv_g1s_kernel"] * 6, seen
     with torch.no_grad():
         ref = ohub.extract_features(sd, cfg, wav, 12)
