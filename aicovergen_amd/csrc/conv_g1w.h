@@ -122,64 +122,67 @@ __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1w_kernel(
     const float pre_slope = p.pre_slope;
     auto lrelu = [&](float v) __attribute__((always_inline)) { return PRE ? fmaxf(v, v * pre_slope) : v; };
 
-    // One unit: group G of the kernel on the 8 channels at rows `rb` .. `rb` + 7 of the window at `wbuf`, weights at `abuf`.
-    // k-step s contracts channels rb + 2 s + half.  Per k-step: the window quads the group's two tiles need, the leaky ReLU and B^T d in
-    // registers, 2 x slots MFMAs.  HALF = 0: k-steps 0, 1; 1: k-steps 2, 3 (the barrier of the pipeline sits between them).
-    auto unit_half = [&](auto g_tag, auto half_tag, const float* abuf, const float* wbuf, int rb) __attribute__((always_inline)) {
+    // ---- the k-step pipeline.  A k-step of unit (cs, v) -- group G, channels rb + 2 s + half of the stage's window -- has two parts:
+    //   prep: the window quads the group's two tiles need (<= 3 ds_read_b128), the leaky ReLU and B^T d in registers -> V[tile][slot]
+    //   mma : 2 x slots MFMAs with the unit's A fragments (one float4 per slot = its four k-steps)
+    // and prep of k-step i + 1 is issued in front of the MFMAs of k-step i (across unit and stage boundaries), so that LDS latency and
+    // the transform's VALU sit under 512 cycles of matrix pipe instead of in front of them.
+    auto prep = [&](auto g_tag, int s, const float* wbuf, int rb, float (&V)[2][4]) __attribute__((always_inline)) {
         constexpr int G = decltype(g_tag)::value;
-        constexpr int H = decltype(half_tag)::value;
         constexpr int NS = PL::slots_of(G);
         constexpr int I0 = PL::DELTA + 3 * G;              // element of the quad run that is d0 of tile 0
         constexpr int Q0 = I0 / 4, Q1 = (I0 + 2 + 3) / 4;  // quads the two tiles' d0 .. d3 live in (tile 1 is two positions on)
         constexpr int NQ = Q1 - Q0 + 1;
+        constexpr int base = I0 - 4 * Q0;
         static_assert(NQ <= 3, "two tiles of a group span at most three quads");
-        float4 a[NS];
-        {
-            const float4* wt = reinterpret_cast<const float4*>(__builtin_assume_aligned(abuf, 16)) + a_lane;
+        float4 q[5];
+        const float4* xt = reinterpret_cast<const float4*>(__builtin_assume_aligned(wbuf, 16)) + b_lane + (rb + 2 * s) * RQ + Q0;
 #pragma unroll
-            for (int sl = 0; sl < NS; ++sl) a[sl] = wt[sl * 2 * BM];
+        for (int t = 0; t < NQ; ++t) q[t] = xt[t];
+        const float w0 = lrelu(g1w_w<base + 0>(q)), w1 = lrelu(g1w_w<base + 1>(q)), w2 = lrelu(g1w_w<base + 2>(q));
+        const float w3 = lrelu(g1w_w<base + 3>(q)), w4 = lrelu(g1w_w<base + 4>(q)), w5 = lrelu(g1w_w<base + 5>(q));
+        const float d[2][4] = {{w0, w1, w2, w3}, {w2, w3, w4, w5}};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if constexpr (NS == 4) {
+                V[j][0] = d[j][0] - d[j][2]; V[j][1] = d[j][1] + d[j][2]; V[j][2] = d[j][2] - d[j][1]; V[j][3] = d[j][1] - d[j][3];
+            } else if constexpr (NS == 3) {                // two taps (a, b): slots a -> M0, a + b -> M1, b -> M3
+                V[j][0] = d[j][0] - d[j][1]; V[j][1] = d[j][1]; V[j][2] = d[j][1] - d[j][2]; V[j][3] = 0.f;
+            } else {                                       // one tap a: slots a -> M0, -a -> M3
+                V[j][0] = d[j][0]; V[j][1] = d[j][1]; V[j][2] = 0.f; V[j][3] = 0.f;
+            }
         }
+    };
+    auto load_a = [&](auto g_tag, const float* abuf, float4 (&a)[4]) __attribute__((always_inline)) {
+        constexpr int NS = PL::slots_of(decltype(g_tag)::value);
+        const float4* wt = reinterpret_cast<const float4*>(__builtin_assume_aligned(abuf, 16)) + a_lane;
 #pragma unroll
-        for (int s = 2 * H; s < 2 * H + 2; ++s) {
-            float4 q[5];
-            const float4* xt = reinterpret_cast<const float4*>(__builtin_assume_aligned(wbuf, 16)) + b_lane + (rb + 2 * s) * RQ + Q0;
+        for (int sl = 0; sl < NS; ++sl) a[sl] = wt[sl * 2 * BM];
+    };
+    auto mma = [&](auto g_tag, int s, const float4 (&a)[4], const float (&V)[2][4]) __attribute__((always_inline)) {
+        constexpr int NS = PL::slots_of(decltype(g_tag)::value);
+        auto av = [&](int sl) __attribute__((always_inline)) { return s == 0 ? a[sl].x : s == 1 ? a[sl].y : s == 2 ? a[sl].z : a[sl].w; };
 #pragma unroll
-            for (int t = 0; t < NQ; ++t) q[t] = xt[t];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                constexpr int base = I0 - 4 * Q0;
-                float d[4];
-                // (unrolled by hand: the index must be a constant expression)
-                if (j == 0) {
-                    d[0] = lrelu(g1w_w<base + 0>(q)); d[1] = lrelu(g1w_w<base + 1>(q)); d[2] = lrelu(g1w_w<base + 2>(q)); d[3] = lrelu(g1w_w<base + 3>(q));
-                } else {
-                    d[0] = lrelu(g1w_w<base + 2>(q)); d[1] = lrelu(g1w_w<base + 3>(q)); d[2] = lrelu(g1w_w<base + 4>(q)); d[3] = lrelu(g1w_w<base + 5>(q));
-                }
-                auto av = [&](int sl) __attribute__((always_inline)) {
-                    return s == 0 ? a[sl].x : s == 1 ? a[sl].y : s == 2 ? a[sl].z : a[sl].w;
-                };
-                if constexpr (NS == 4) {
-                    M[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av(0), d[0] - d[2], M[0][j], 0, 0, 0);
-                    M[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av(1), d[1] + d[2], M[1][j], 0, 0, 0);
-                    M[2][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av(2), d[2] - d[1], M[2][j], 0, 0, 0);
-                    M[3][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av(3), d[1] - d[3], M[3][j], 0, 0, 0);
-                } else if constexpr (NS == 3) {            // two taps (a, b): slots a, a + b, b
-                    M[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av(0), d[0] - d[1], M[0][j], 0, 0, 0);
-                    M[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av(1), d[1], M[1][j], 0, 0, 0);
-                    M[3][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av(2), d[1] - d[2], M[3][j], 0, 0, 0);
-                } else {                                   // one tap a: slots a, -a
-                    M[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av(0), d[0], M[0][j], 0, 0, 0);
-                    M[3][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av(1), d[1], M[3][j], 0, 0, 0);
-                }
+        for (int j = 0; j < 2; ++j) {
+            if constexpr (NS == 4) {
+                M[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av(0), V[j][0], M[0][j], 0, 0, 0);
+                M[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av(1), V[j][1], M[1][j], 0, 0, 0);
+                M[2][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av(2), V[j][2], M[2][j], 0, 0, 0);
+                M[3][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av(3), V[j][3], M[3][j], 0, 0, 0);
+            } else if constexpr (NS == 3) {
+                M[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av(0), V[j][0], M[0][j], 0, 0, 0);
+                M[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av(1), V[j][1], M[1][j], 0, 0, 0);
+                M[3][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av(2), V[j][2], M[3][j], 0, 0, 0);
+            } else {
+                M[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av(0), V[j][0], M[0][j], 0, 0, 0);
+                M[3][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av(1), V[j][1], M[3][j], 0, 0, 0);
             }
         }
     };
 
     // ---- the unit pipeline.  Unit index u = cs NU + v; weights ring a[u % 3], window bbuf[cs & 1].
-    auto unit_of = [&](int u, int& cs, int& v) __attribute__((always_inline)) { cs = u / PL::NU; v = u - cs * PL::NU; };
     auto issue_unit_a = [&](int u, float* abuf) __attribute__((always_inline)) {
-        int cs, v;
-        unit_of(u, cs, v);
+        const int cs = u / PL::NU, v = u - cs * PL::NU;
         if constexpr (K == 3) issue_a(cs * 2 + v, 0, 4, abuf);
         else issue_a(cs, 4 * v, v < PL::NFULL ? 4 : PL::slots_of(PL::NFULL), abuf);
     };
@@ -192,32 +195,73 @@ __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1w_kernel(
     if (nunits > 1) issue_unit_a(1, a_nxt);
     g1_wait_pieces<0>();
     lds_barrier();
-    // one unit of the walk, v known at compile time; LAST: nothing to publish or to issue behind it
-    auto run_unit = [&](auto v_tag, int cs, int u, bool last) __attribute__((always_inline)) {
+    float4 af[4], an[4];                                  // A fragments of the running unit / of the next one
+    float Vc[2][4], Vn[2][4];                             // operands of the running k-step / of the next one
+    load_a(std::integral_constant<int, 0>{}, a_cur, af);
+    prep(std::integral_constant<int, 0>{}, 0, bbuf, 0, Vc);
+    // one unit of the walk; V (unit inside the stage) and LASTU (the walk's last unit: nothing behind it) at compile time
+    auto run_unit = [&](auto v_tag, auto last_tag, int cs, int u) __attribute__((always_inline)) {
         constexpr int V = decltype(v_tag)::value;
+        constexpr bool LASTU = decltype(last_tag)::value;
         constexpr int G = K == 3 ? 0 : V;
-        const int rb = K == 3 ? 8 * V : 0;
+        constexpr int VN = (V + 1) % PL::NU, GN = K == 3 ? 0 : VN;      // the unit behind this one
+        using GT = std::integral_constant<int, G>;
+        using GNT = std::integral_constant<int, GN>;
+        const int rb = K == 3 ? 8 * V : 0, rbn = K == 3 ? 8 * VN : 0;
         const float* wbuf = bbuf + (cs & 1) * BSTAGE;
+        const float* wnxt = bbuf + ((V + 1 == PL::NU ? cs + 1 : cs) & 1) * BSTAGE;
+        // k-steps 0 and 1
+        prep(GT{}, 1, wbuf, rb, Vn);
         w2d_fence();
-        unit_half(std::integral_constant<int, G>{}, std::integral_constant<int, 0>{}, a_cur, wbuf, rb);
+        mma(GT{}, 0, af, Vc);
         w2d_fence();
-        if (!last) {
+        prep(GT{}, 2, wbuf, rb, Vc);
+        w2d_fence();
+        mma(GT{}, 1, af, Vn);
+        w2d_fence();
+        if constexpr (!LASTU) {
             g1_wait_pieces<0>();   // this wave's pieces of unit u + 1 (and, issued in front of them, the next stage's window)
-            lds_barrier();
-            if (V == 0 && cs + 1 < nst) issue_b(cs + 1, bbuf + ((cs + 1) & 1) * BSTAGE);   // every wave is past stage cs - 1
+            lds_barrier();         // unit u + 1 (and, behind a stage's last unit, the next window) is complete; unit u - 1's buffer is free
+            if (V == 0 && cs + 1 < nst) issue_b(cs + 1, bbuf + ((cs + 1) & 1) * BSTAGE);
             if (u + 2 < nunits) issue_unit_a(u + 2, a_fill);
+            load_a(GNT{}, a_nxt, an);
         }
+        // k-steps 2 and 3
+        prep(GT{}, 3, wbuf, rb, Vn);
         w2d_fence();
-        unit_half(std::integral_constant<int, G>{}, std::integral_constant<int, 1>{}, a_cur, wbuf, rb);
+        mma(GT{}, 2, af, Vc);
         w2d_fence();
+        if constexpr (!LASTU) prep(GNT{}, 0, wnxt, rbn, Vc);
+        w2d_fence();
+        mma(GT{}, 3, af, Vn);
+        w2d_fence();
+        if constexpr (!LASTU) {
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) af[sl] = an[sl];
+        }
         float* t = a_cur; a_cur = a_nxt; a_nxt = a_fill; a_fill = t;
     };
-    for (int cs = 0; cs < nst; ++cs) {
+    using F = std::false_type;
+    using T = std::true_type;
+    for (int cs = 0; cs + 1 < nst; ++cs) {
         const int u0 = cs * PL::NU;
-        run_unit(std::integral_constant<int, 0>{}, cs, u0, u0 + 1 == nunits);
-        if constexpr (PL::NU > 1) run_unit(std::integral_constant<int, 1>{}, cs, u0 + 1, u0 + 2 == nunits);
-        if constexpr (PL::NU > 2) run_unit(std::integral_constant<int, 2>{}, cs, u0 + 2, u0 + 3 == nunits);
-        if constexpr (PL::NU > 3) run_unit(std::integral_constant<int, 3>{}, cs, u0 + 3, u0 + 4 == nunits);
+        run_unit(std::integral_constant<int, 0>{}, F{}, cs, u0);
+        if constexpr (PL::NU > 1) run_unit(std::integral_constant<int, 1>{}, F{}, cs, u0 + 1);
+        if constexpr (PL::NU > 2) run_unit(std::integral_constant<int, 2>{}, F{}, cs, u0 + 2);
+        if constexpr (PL::NU > 3) run_unit(std::integral_constant<int, 3>{}, F{}, cs, u0 + 3);
+    }
+    {   // the last stage, peeled: its last unit has nothing behind it
+        const int cs = nst - 1, u0 = cs * PL::NU;
+        if constexpr (PL::NU == 1) run_unit(std::integral_constant<int, 0>{}, T{}, cs, u0);
+        if constexpr (PL::NU == 2) { run_unit(std::integral_constant<int, 0>{}, F{}, cs, u0); run_unit(std::integral_constant<int, 1>{}, T{}, cs, u0 + 1); }
+        if constexpr (PL::NU == 3) {
+            run_unit(std::integral_constant<int, 0>{}, F{}, cs, u0); run_unit(std::integral_constant<int, 1>{}, F{}, cs, u0 + 1);
+            run_unit(std::integral_constant<int, 2>{}, T{}, cs, u0 + 2);
+        }
+        if constexpr (PL::NU == 4) {
+            run_unit(std::integral_constant<int, 0>{}, F{}, cs, u0); run_unit(std::integral_constant<int, 1>{}, F{}, cs, u0 + 1);
+            run_unit(std::integral_constant<int, 2>{}, F{}, cs, u0 + 2); run_unit(std::integral_constant<int, 3>{}, T{}, cs, u0 + 3);
+        }
     }
     // ---- A^T: the lane's four consecutive outputs per row, then conv_g1.h's epilogue
     f32x16 y[1][4];
@@ -267,6 +311,5 @@ static int launch_conv_g1w(ConvArgs& p, hipStream_t stream) {
 // instantiation unit conv_g1w_1.hip
 int run_g1w_64x256(ConvArgs& p, hipStream_t st);    // 2 x 2 waves of 32 rows x 128 outputs
 int run_g1w_32x512(ConvArgs& p, hipStream_t st);    // 1 x 4 waves: the 32-channel stage
-int run_g1w_128x128(ConvArgs& p, hipStream_t st);   // 4 x 1 waves
 
 }  // namespace aicg

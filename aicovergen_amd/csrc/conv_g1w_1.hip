@@ -3,5 +3,4 @@
 namespace aicg {
 int run_g1w_64x256(ConvArgs& p, hipStream_t st) { return launch_conv_g1w<2, 2, 2>(p, st); }
 int run_g1w_32x512(ConvArgs& p, hipStream_t st) { return launch_conv_g1w<1, 4, 2>(p, st); }
-int run_g1w_128x128(ConvArgs& p, hipStream_t st) { return launch_conv_g1w<4, 1, 2>(p, st); }
 }  // namespace aicg
