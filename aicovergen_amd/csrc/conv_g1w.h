@@ -56,7 +56,17 @@ __device__ __forceinline__ float g1w_w(const float4 (&q)[5]) {        // W[I] ou
     return e == 0 ? q[qi].x : e == 1 ? q[qi].y : e == 2 ? q[qi].z : q[qi].w;
 }
 
-template <int K, int WM, int WN, int WPS, bool PRE>
+// One scheduling group of `n` instructions of class `mask` (0x008 MFMA, 0x002 VALU, 0x100 LDS read) in the running scheduling region
+#ifdef AICG_EMULATED
+#define AICG_SCHED_GROUP(mask, n) ((void)0)
+#else
+#define AICG_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
+#endif
+
+// SCH: the k-step regions carry an explicit interleave -- the next k-step's window reads in front of the first MFMA, its leaky ReLU and
+// B^T d four VALU instructions at a time behind each of the following MFMAs -- instead of [prep][8 MFMAs] blocks (a wave issues in order:
+// left as blocks, the ~25 VALU instructions of a prep sit between two MFMA bursts with this wave's share of the matrix pipe idle).
+template <int K, int WM, int WN, int WPS, bool PRE, int SCH = 0>
 __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1w_kernel(ConvArgs p) {
     using PL = G1wPlan<K>;
     static_assert(WM * WN == 4, "four waves");
@@ -120,7 +130,15 @@ __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1w_kernel(
     const int a_lane = half * BM + wm * 32 + l31;          // float4 index inside a slot's slab pair
     const int b_lane = half * RQ + wn * 32 + l31;          // float4 index of the lane's first window quad inside a row pair
     const float pre_slope = p.pre_slope;
-    auto lrelu = [&](float v) __attribute__((always_inline)) { return PRE ? fmaxf(v, v * pre_slope) : v; };
+    // lrelu(v) = max(v, slope v) for 0 <= slope <= 1, as ONE v_med3_f32 behind the multiply: fmaxf() would add a canonicalising v_max(x, x)
+    // per value (IEEE maxnum quiets signalling NaNs); med3(a, b, +inf) = max(a, b) for non-NaN operands, same bits
+    auto lrelu = [&](float v) __attribute__((always_inline)) {
+#ifdef AICG_EMULATED
+        return PRE ? fmaxf(v, v * pre_slope) : v;
+#else
+        return PRE ? __builtin_amdgcn_fmed3f(v, v * pre_slope, __builtin_inff()) : v;
+#endif
+    };
 
     // ---- the k-step pipeline.  A k-step of unit (cs, v) -- group G, channels rb + 2 s + half of the stage's window -- has two parts:
     //   prep: the window quads the group's two tiles need (<= 3 ds_read_b128), the leaky ReLU and B^T d in registers -> V[tile][slot]
@@ -210,14 +228,29 @@ __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1w_kernel(
         const int rb = K == 3 ? 8 * V : 0, rbn = K == 3 ? 8 * VN : 0;
         const float* wbuf = bbuf + (cs & 1) * BSTAGE;
         const float* wnxt = bbuf + ((V + 1 == PL::NU ? cs + 1 : cs) & 1) * BSTAGE;
+        // (a k-step region: prep of the next k-step + the MFMAs of this one, interleaved when SCH)
+        auto interleave = [&]() __attribute__((always_inline)) {
+            if constexpr (SCH != 0) {
+                AICG_SCHED_GROUP(0x100, 3);
+                AICG_SCHED_GROUP(0x008, 1);
+                AICG_SCHED_GROUP(0x002, 2);
+                AICG_SCHED_GROUP(0x008, 1);
+#pragma unroll
+                for (int e = 0; e < 6; ++e) { AICG_SCHED_GROUP(0x002, 4); AICG_SCHED_GROUP(0x008, 1); }
+                AICG_SCHED_GROUP(0x002, 8);
+            }
+        };
         // k-steps 0 and 1
-        prep(GT{}, 1, wbuf, rb, Vn);
         w2d_fence();
+        prep(GT{}, 1, wbuf, rb, Vn);
+        if constexpr (SCH == 0) w2d_fence();
         mma(GT{}, 0, af, Vc);
+        interleave();
         w2d_fence();
         prep(GT{}, 2, wbuf, rb, Vc);
-        w2d_fence();
+        if constexpr (SCH == 0) w2d_fence();
         mma(GT{}, 1, af, Vn);
+        interleave();
         w2d_fence();
         if constexpr (!LASTU) {
             g1_wait_pieces<0>();   // this wave's pieces of unit u + 1 (and, issued in front of them, the next stage's window)
@@ -227,13 +260,16 @@ __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1w_kernel(
             load_a(GNT{}, a_nxt, an);
         }
         // k-steps 2 and 3
-        prep(GT{}, 3, wbuf, rb, Vn);
         w2d_fence();
+        prep(GT{}, 3, wbuf, rb, Vn);
+        if constexpr (SCH == 0) w2d_fence();
         mma(GT{}, 2, af, Vc);
+        interleave();
         w2d_fence();
         if constexpr (!LASTU) prep(GNT{}, 0, wnxt, rbn, Vc);
-        w2d_fence();
+        if constexpr (SCH == 0) w2d_fence();
         mma(GT{}, 3, af, Vn);
+        if constexpr (!LASTU) interleave();
         w2d_fence();
         if constexpr (!LASTU) {
 #pragma unroll
@@ -288,7 +324,7 @@ inline bool conv_g1w_applicable(const ConvArgs& p, int pad_w_end) {
     return true;
 }
 
-template <int WM, int WN, int WPS>
+template <int WM, int WN, int WPS, int SCH = 0>
 static int launch_conv_g1w(ConvArgs& p, hipStream_t stream) {
     constexpr int BM = 32 * WM, BN = 128 * WN;
     p.tiles_h = idiv_up(p.Cout_g, BM);
@@ -300,9 +336,9 @@ static int launch_conv_g1w(ConvArgs& p, hipStream_t stream) {
     if (lds > 160 * 1024) return 1;
     const bool pre = p.pre_act != AICG_ACT_NONE;
     void (*kern)(ConvArgs) = nullptr;
-    if (p.KW == 3) kern = pre ? conv_g1w_kernel<3, WM, WN, WPS, true> : conv_g1w_kernel<3, WM, WN, WPS, false>;
-    else if (p.KW == 7) kern = pre ? conv_g1w_kernel<7, WM, WN, WPS, true> : conv_g1w_kernel<7, WM, WN, WPS, false>;
-    else kern = pre ? conv_g1w_kernel<11, WM, WN, WPS, true> : conv_g1w_kernel<11, WM, WN, WPS, false>;
+    if (p.KW == 3) kern = pre ? conv_g1w_kernel<3, WM, WN, WPS, true, SCH> : conv_g1w_kernel<3, WM, WN, WPS, false, SCH>;
+    else if (p.KW == 7) kern = pre ? conv_g1w_kernel<7, WM, WN, WPS, true, SCH> : conv_g1w_kernel<7, WM, WN, WPS, false, SCH>;
+    else kern = pre ? conv_g1w_kernel<11, WM, WN, WPS, true, SCH> : conv_g1w_kernel<11, WM, WN, WPS, false, SCH>;
     allow_dynamic_lds((const void*)kern, lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, stream, p);
     return check_launch("conv_g1w_kernel");
@@ -310,6 +346,7 @@ static int launch_conv_g1w(ConvArgs& p, hipStream_t stream) {
 
 // instantiation unit conv_g1w_1.hip
 int run_g1w_64x256(ConvArgs& p, hipStream_t st);    // 2 x 2 waves of 32 rows x 128 outputs
-int run_g1w_32x512(ConvArgs& p, hipStream_t st);    // 1 x 4 waves: the 32-channel stage
+int run_g1w_32x512(ConvArgs& p, hipStream_t st);    // 1 x 4 waves: all four share the tile's 32 rows
+int run_g1w_32x512_sched(ConvArgs& p, hipStream_t st);   // ... with the explicit MFMA / VALU interleave (SCH)
 
 }  // namespace aicg
