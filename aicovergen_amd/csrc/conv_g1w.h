@@ -33,21 +33,27 @@
 
 namespace aicg {
 
-template <int K>
+template <int K, int D = 1>
 struct G1wPlan {
     static_assert(K == 3 || K == 7 || K == 11, "kernel sizes of the vocoder's ResBlocks");
+    static_assert(D == 1 || D == 3 || D == 5, "dilations of the vocoder's ResBlocks");
     static constexpr int P = (K - 1) / 2;
     static constexpr int NFULL = K / 3, REM = K % 3;            // 3-tap groups, remainder taps
     static constexpr int NG = NFULL + (REM ? 1 : 0);            // slot groups
     static constexpr int NSLOT = 4 * NFULL + (REM == 2 ? 3 : REM == 1 ? 2 : 0);
     static constexpr int CS = K == 3 ? 16 : 8;                  // channels per window stage
     static constexpr int NU = K == 3 ? 2 : NG;                  // units per stage
-    static constexpr int BACK = (P + 3) / 4;                    // quads the window starts below n0
-    static constexpr int DELTA = 4 * BACK - P;                  // W[i] = row[4 (quad of the lane) + DELTA + i]
+    static constexpr int BACK = (P * D + 3) / 4;                // quads the window starts below n0
+    static constexpr int DELTA = 4 * BACK - P * D;              // W[i] = row[(first output of the lane) + DELTA + i D]
+    // Outputs a wave owns.  D = 1: 128 (lane l: 4 l .. 4 l + 3).  D > 1: the pairs are (n, n + D), so a lane owns the progression
+    // n_l + {0, D, 2 D, 3 D}, n_l = 4 D (l / D) + l % D: blocks of 4 D outputs, 30 of the 32 lanes (120 outputs) for D = 3 and 5 alike
+    static constexpr int SPAN = D == 1 ? 128 : 120;
+    static constexpr int LANES = D == 1 ? 32 : 30;
     __host__ __device__ static constexpr int slots_of(int g) { return g < NFULL ? 4 : (REM == 2 ? 3 : 2); }
 };
 
-__host__ __device__ constexpr int g1w_row_quads(int bn) { return bn / 4 + 4; }
+// quads per window row: positions n0 - 4 BACK .. n0 + bn - 1 + P D (+ the quad a run may end in)
+__host__ __device__ constexpr int g1w_row_quads(int bn, int k, int d) { return (bn + 4 * (((k - 1) / 2 * d + 3) / 4) + (k - 1) / 2 * d + 3) / 4 + 1; }
 
 template <int I>
 __device__ __forceinline__ float g1w_w(const float4 (&q)[5]) {        // W[I] out of the loaded quads (element DELTA + I of the run)
@@ -66,12 +72,12 @@ __device__ __forceinline__ float g1w_w(const float4 (&q)[5]) {        // W[I] ou
 // SCH: the k-step regions carry an explicit interleave -- the next k-step's window reads in front of the first MFMA, its leaky ReLU and
 // B^T d four VALU instructions at a time behind each of the following MFMAs -- instead of [prep][8 MFMAs] blocks (a wave issues in order:
 // left as blocks, the ~25 VALU instructions of a prep sit between two MFMA bursts with this wave's share of the matrix pipe idle).
-template <int K, int WM, int WN, int WPS, bool PRE, int SCH = 0>
+template <int K, int D, int WM, int WN, int WPS, bool PRE, int SCH = 0>
 __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1w_kernel(ConvArgs p) {
-    using PL = G1wPlan<K>;
+    using PL = G1wPlan<K, D>;
     static_assert(WM * WN == 4, "four waves");
-    constexpr int BM = 32 * WM, BN = 128 * WN;
-    constexpr int RQ = g1w_row_quads(BN);
+    constexpr int BM = 32 * WM, BN = PL::SPAN * WN;
+    constexpr int RQ = g1w_row_quads(BN, K, D);
     constexpr int ASTAGE = 4 * 2 * BM * 4;               // floats: <= 4 slots x 2 parities x BM quads
     constexpr int BQ = PL::CS * RQ, NB = (BQ + 63) / 64, BSTAGE = NB * 256;
     HIP_DYNAMIC_SHARED(float4, smem4)
@@ -128,7 +134,11 @@ __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1w_kernel(
             for (int r = 0; r < 16; ++r) M[q][j][r] = 0.f;
 
     const int a_lane = half * BM + wm * 32 + l31;          // float4 index inside a slot's slab pair
-    const int b_lane = half * RQ + wn * 32 + l31;          // float4 index of the lane's first window quad inside a row pair
+    const int b_lane = half * RQ + wn * 32 + l31;          // D = 1: float4 index of the lane's first window quad inside a row pair
+    // D > 1: first output of the lane inside the wave's span, and the float index of its W[0] inside a row pair
+    const int la = l31 < PL::LANES ? l31 : PL::LANES - 1;  // (lanes 30, 31 shadow lane 29; their results are not stored)
+    const int n_lane = 4 * D * (la / D) + la % D;
+    const int f_lane = half * RQ * 4 + wn * PL::SPAN + n_lane + PL::DELTA;
     const float pre_slope = p.pre_slope;
     // lrelu(v) = max(v, slope v) for 0 <= slope <= 1, as ONE v_med3_f32 behind the multiply: fmaxf() would add a canonicalising v_max(x, x)
     // per value (IEEE maxnum quiets signalling NaNs); med3(a, b, +inf) = max(a, b) for non-NaN operands, same bits
@@ -153,12 +163,19 @@ __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1w_kernel(
         constexpr int NQ = Q1 - Q0 + 1;
         constexpr int base = I0 - 4 * Q0;
         static_assert(NQ <= 3, "two tiles of a group span at most three quads");
-        float4 q[5];
-        const float4* xt = reinterpret_cast<const float4*>(__builtin_assume_aligned(wbuf, 16)) + b_lane + (rb + 2 * s) * RQ + Q0;
+        float w0, w1, w2, w3, w4, w5;
+        if constexpr (D == 1) {
+            float4 q[5];
+            const float4* xt = reinterpret_cast<const float4*>(__builtin_assume_aligned(wbuf, 16)) + b_lane + (rb + 2 * s) * RQ + Q0;
 #pragma unroll
-        for (int t = 0; t < NQ; ++t) q[t] = xt[t];
-        const float w0 = lrelu(g1w_w<base + 0>(q)), w1 = lrelu(g1w_w<base + 1>(q)), w2 = lrelu(g1w_w<base + 2>(q));
-        const float w3 = lrelu(g1w_w<base + 3>(q)), w4 = lrelu(g1w_w<base + 4>(q)), w5 = lrelu(g1w_w<base + 5>(q));
+            for (int t = 0; t < NQ; ++t) q[t] = xt[t];
+            w0 = lrelu(g1w_w<base + 0>(q)); w1 = lrelu(g1w_w<base + 1>(q)); w2 = lrelu(g1w_w<base + 2>(q));
+            w3 = lrelu(g1w_w<base + 3>(q)); w4 = lrelu(g1w_w<base + 4>(q)); w5 = lrelu(g1w_w<base + 5>(q));
+        } else {
+            // the six values W[3 G + e], e = 0 .. 5, sit D positions apart: six ds_read_b32 at immediate offsets from the lane's base
+            const float* xr = wbuf + f_lane + (rb + 2 * s) * RQ * 4 + 3 * G * D;
+            w0 = lrelu(xr[0]); w1 = lrelu(xr[D]); w2 = lrelu(xr[2 * D]); w3 = lrelu(xr[3 * D]); w4 = lrelu(xr[4 * D]); w5 = lrelu(xr[5 * D]);
+        }
         const float d[2][4] = {{w0, w1, w2, w3}, {w2, w3, w4, w5}};
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -299,7 +316,7 @@ __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1w_kernel(
             run_unit(std::integral_constant<int, 2>{}, F{}, cs, u0 + 2); run_unit(std::integral_constant<int, 3>{}, T{}, cs, u0 + 3);
         }
     }
-    // ---- A^T: the lane's four consecutive outputs per row, then conv_g1.h's epilogue
+    // ---- A^T: the lane's four outputs per row
     f32x16 y[1][4];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -308,15 +325,64 @@ __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1w_kernel(
         y[0][2][r] = (M[0][1][r] + M[1][1][r]) + M[2][1][r];
         y[0][3][r] = (M[1][1][r] - M[2][1][r]) - M[3][1][r];
     }
-    g1_epilogue<1, false, false>(p, y, img, m_base + wm * 32, n0 + wn * 128 + 4 * l31, p.Wo);
+    if constexpr (D == 1) {
+        // four CONSECUTIVE outputs: conv_g1.h's float4 epilogue
+        g1_epilogue<1, false, false>(p, y, img, m_base + wm * 32, n0 + wn * 128 + 4 * l31, p.Wo);
+    } else {
+        // the outputs n_l + {0, D, 2 D, 3 D}: through a per-wave LDS tile [32 rows][SPAN + 4] (the pipeline's buffers are free: every wave
+        // is past the last unit's barrier ... after one more), read back as float4 runs of a row -- 15 per lane -- and stored with the
+        // bias / activation / residual / accumulate arithmetic of conv_g1.h's epilogue
+        constexpr int LD = PL::SPAN + 4;
+        lds_barrier();
+        float* tile = smem + wave * 32 * LD;
+        if (l31 < PL::LANES) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float* row = tile + (8 * (r >> 2) + 4 * half + (r & 3)) * LD + n_lane;
+                row[0] = y[0][0][r]; row[D] = y[0][1][r]; row[2 * D] = y[0][2][r]; row[3 * D] = y[0][3][r];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();   // (a wave's LDS accesses are processed in order; the emulator's lanes rendezvous here)
+        const int m0 = m_base + wm * 32, nw = n0 + wn * PL::SPAN;
+        auto body = [&](auto act_tag) __attribute__((always_inline)) {
+            constexpr int ACT = decltype(act_tag)::value;
+            for (int idx = lane; idx < 32 * (PL::SPAN / 4); idx += 64) {
+                const int rw = idx / (PL::SPAN / 4), q4 = idx - rw * (PL::SPAN / 4);
+                const int m = m0 + rw, pos = nw + 4 * q4;
+                if (m >= p.Cout_g || pos >= p.Wo) continue;          // (Wo % 4 == 0: a quad is inside the row or outside)
+                const float4 v4 = *reinterpret_cast<const float4*>(tile + rw * LD + 4 * q4);
+                const float bv = p.bias ? p.bias[m] : 0.f;
+                float v[4] = {v4.x + bv, v4.y + bv, v4.z + bv, v4.w + bv};
+                float4 rv = make_float4(0.f, 0.f, 0.f, 0.f), yv = make_float4(0.f, 0.f, 0.f, 0.f);
+                float* dst = p.y + (long)img * p.y_sn + (long)m * p.y_sc + pos;
+                if (p.res) rv = *reinterpret_cast<const float4*>(p.res + (long)img * p.r_sn + (long)m * p.r_sc + pos);
+                if (p.accumulate) yv = *reinterpret_cast<const float4*>(dst);
+                const float rr[4] = {rv.x, rv.y, rv.z, rv.w}, yy[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    float x = v[t];
+                    if (p.res_first) x += rr[t];
+                    x = act_static<ACT>(x, p.act, p.act_slope);
+                    if (!p.res_first) x += rr[t];
+                    v[t] = x * p.out_scale + yy[t];
+                }
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        };
+        if (p.act == AICG_ACT_NONE) body(std::integral_constant<int, 0>{});
+        else if (p.act == AICG_ACT_RELU) body(std::integral_constant<int, 1>{});
+        else if (p.act == AICG_ACT_LRELU) body(std::integral_constant<int, 2>{});
+        else body(std::integral_constant<int, 3>{});
+    }
 }
 
 // host side: a 1-D layer of the form this kernel takes
 inline bool conv_g1w_applicable(const ConvArgs& p, int pad_w_end) {
     auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     auto m4 = [](long v) { return (v & 3) == 0; };
-    if (p.KH != 1 || p.H != 1 || p.Ho != 1 || (p.KW != 3 && p.KW != 7 && p.KW != 11) || p.groups != 1 || p.sw != 1 || p.dw != 1 || !p.w3) return false;
-    if (p.pw != (p.KW - 1) / 2 || pad_w_end != p.pw || p.ph || p.Wo != p.W || (p.W & 3) || p.Cin_g < 16) return false;
+    if (p.KH != 1 || p.H != 1 || p.Ho != 1 || (p.KW != 3 && p.KW != 7 && p.KW != 11) || p.groups != 1 || p.sw != 1 || !p.w3) return false;
+    if (p.dw != 1 && p.dw != 3 && p.dw != 5) return false;
+    if (p.pw != (p.KW - 1) / 2 * p.dw || pad_w_end != p.pw || p.ph || p.Wo != p.W || (p.W & 3) || p.Cin_g < 16) return false;
     if (p.pre_act != AICG_ACT_NONE && !(p.pre_act == AICG_ACT_LRELU && p.pre_slope >= 0.f && p.pre_slope <= 1.f)) return false;
     if (p.shuffle || p.res_mul || p.W >= (1 << 24) || p.x_sc >= (1L << 24) || p.x_sc < p.W) return false;
     if (!al(p.x) || !m4(p.x_sn) || !m4(p.x_sc) || !al(p.y) || !m4(p.y_sn) || !m4(p.y_sc)) return false;
@@ -324,24 +390,41 @@ inline bool conv_g1w_applicable(const ConvArgs& p, int pad_w_end) {
     return true;
 }
 
-template <int WM, int WN, int WPS, int SCH = 0>
-static int launch_conv_g1w(ConvArgs& p, hipStream_t stream) {
-    constexpr int BM = 32 * WM, BN = 128 * WN;
+template <int K, int D, int WM, int WN, int WPS, int SCH>
+static int launch_conv_g1w_kd(ConvArgs& p, hipStream_t stream) {
+    using PL = G1wPlan<K, D>;
+    constexpr int BM = 32 * WM, BN = PL::SPAN * WN;
     p.tiles_h = idiv_up(p.Cout_g, BM);
     p.tiles_w = idiv_up(p.Wo, BN);
     const long nwg = (long)p.N * p.tiles_h * p.tiles_w;
     if (nwg > 2147483647L) return fail(AICG_E_SHAPE, "conv: too many output tiles");
-    const int cs = p.KW == 3 ? 16 : 8;
-    const size_t lds = (size_t)(3 * 4 * 2 * BM * 4 + 2 * ((cs * g1w_row_quads(BN) + 63) / 64) * 256) * sizeof(float);
+    size_t lds = (size_t)(3 * 4 * 2 * BM * 4 + 2 * ((PL::CS * g1w_row_quads(BN, K, D) + 63) / 64) * 256) * sizeof(float);
+    if (D > 1 && lds < (size_t)4 * 32 * (PL::SPAN + 4) * sizeof(float)) lds = (size_t)4 * 32 * (PL::SPAN + 4) * sizeof(float);   // the epilogue's tiles
     if (lds > 160 * 1024) return 1;
-    const bool pre = p.pre_act != AICG_ACT_NONE;
-    void (*kern)(ConvArgs) = nullptr;
-    if (p.KW == 3) kern = pre ? conv_g1w_kernel<3, WM, WN, WPS, true, SCH> : conv_g1w_kernel<3, WM, WN, WPS, false, SCH>;
-    else if (p.KW == 7) kern = pre ? conv_g1w_kernel<7, WM, WN, WPS, true, SCH> : conv_g1w_kernel<7, WM, WN, WPS, false, SCH>;
-    else kern = pre ? conv_g1w_kernel<11, WM, WN, WPS, true, SCH> : conv_g1w_kernel<11, WM, WN, WPS, false, SCH>;
+    auto kern = p.pre_act != AICG_ACT_NONE ? conv_g1w_kernel<K, D, WM, WN, WPS, true, SCH> : conv_g1w_kernel<K, D, WM, WN, WPS, false, SCH>;
     allow_dynamic_lds((const void*)kern, lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, stream, p);
     return check_launch("conv_g1w_kernel");
+}
+
+template <int WM, int WN, int WPS, int SCH = 0, bool DIL = true>
+static int launch_conv_g1w(ConvArgs& p, hipStream_t stream) {
+    if (p.dw == 1) {
+        if (p.KW == 3) return launch_conv_g1w_kd<3, 1, WM, WN, WPS, SCH>(p, stream);
+        if (p.KW == 7) return launch_conv_g1w_kd<7, 1, WM, WN, WPS, SCH>(p, stream);
+        return launch_conv_g1w_kd<11, 1, WM, WN, WPS, SCH>(p, stream);
+    }
+    if constexpr (DIL) {
+        if (p.dw == 3) {
+            if (p.KW == 3) return launch_conv_g1w_kd<3, 3, WM, WN, WPS, SCH>(p, stream);
+            if (p.KW == 7) return launch_conv_g1w_kd<7, 3, WM, WN, WPS, SCH>(p, stream);
+            return launch_conv_g1w_kd<11, 3, WM, WN, WPS, SCH>(p, stream);
+        }
+        if (p.KW == 3) return launch_conv_g1w_kd<3, 5, WM, WN, WPS, SCH>(p, stream);
+        if (p.KW == 7) return launch_conv_g1w_kd<7, 5, WM, WN, WPS, SCH>(p, stream);
+        return launch_conv_g1w_kd<11, 5, WM, WN, WPS, SCH>(p, stream);
+    }
+    return 1;
 }
 
 // instantiation unit conv_g1w_1.hip

@@ -254,7 +254,7 @@ def winograd2d_image(w, quads=False):
     return Up.view(co // 48, 48, cpad // 8, 2, 4, 16).permute(0, 2, 3, 5, 4, 1).contiguous().view(-1)
 
 
-# One-dimensional Winograd F(2, 3) for the vocoder's k = 3 / 7 / 11 ResBlock layers of dilation 1 (csrc/conv_g1w.h): 4 / 10 / 15 products
+# One-dimensional Winograd F(2, 3) for the vocoder's k = 3 / 7 / 11 ResBlock layers, dilation 1 / 3 / 5 (csrc/conv_g1w.h): 4 / 10 / 15 products
 # per output pair and input channel instead of 6 / 14 / 22.  Layers packed while this is set carry the slot image next to the direct one;
 # conv() takes it where the kernel applies (aligned rows, W % 4 == 0, enough positions).  The f0 models never do (fp32_layers()).
 winograd1d = os.environ.get("AICG_WINOGRAD1D", "1") != "0"
@@ -304,7 +304,8 @@ class PackedConv:
         self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
         self.w_wino = self.w_wino2 = self.w_wino2q = self.w_wino1 = None
         if (winograd1d and not self.split and not _fp32_depth and self.kh == 1 and self.kw in (3, 7, 11) and stride == (1, 1)
-                and dilation == (1, 1) and padding == (0, (self.kw - 1) // 2) and self.padding_end is None and groups == 1 and cin_g >= 16):
+                and dilation[1] in (1, 3, 5) and padding == (0, (self.kw - 1) // 2 * dilation[1]) and self.padding_end is None
+                and groups == 1 and cin_g >= 16):
             # slot image of the 1-D Winograd form, packed like any k-tap kernel (slots in the taps' place)
             self.w_wino1 = pack_conv_weight(winograd1d_kernel(weight.detach().to(device=device, dtype=torch.float32)[:, :, 0]).unsqueeze(2), 1, False)
         if (winograd and not self.split and not _fp32_depth and (self.kh, self.kw) == (3, 3) and stride == (1, 1) and dilation == (1, 1)

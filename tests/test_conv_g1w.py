@@ -1,4 +1,4 @@
-"""The one-dimensional Winograd F(2, 3) convolution (csrc/conv_g1w.h: the vocoder's k = 3 / 7 / 11 ResBlock layers of dilation 1, reference
+"""The one-dimensional Winograd F(2, 3) convolution (csrc/conv_g1w.h: the vocoder's k = 3 / 7 / 11 ResBlock layers, dilation 1 / 3 / 5, reference
 src/infer_pack/modules.py:299-312) against torch fp32: every kernel size, every tile, the ResBlock step x + conv(lrelu(x)), the accumulating
 last step (xs += resblock(x) / 3, models.py:506-512), plain / activated outputs, ragged channel counts, maps of several column tiles with a
 tail, several images, channel-slice operands -- and the routing (dilated, strided, unaligned or short layers stay on the direct kernels).
@@ -47,24 +47,26 @@ def test_slot_kernel_reproduces_the_direct_form():
         assert rel_rms(got, ref) < 1e-6, k
 
 
-def _run(dev, n, ci, co, k, T, tile, mode, seed=0, expect="conv_g1w_kernel"):
+def _run(dev, n, ci, co, k, T, tile, mode, seed=0, expect="conv_g1w_kernel", d=1):
     torch.manual_seed(seed)
     x, w, b = torch.randn(n, ci, T), torch.randn(co, ci, k) * 0.2, torch.randn(co)
-    pc = ops.PackedConv(w, b, padding=(k - 1) // 2, device=dev.device)
+    pad = (k - 1) // 2 * d
+    pc = ops.PackedConv(w, b, padding=pad, dilation=d, device=dev.device)
     assert pc.w_wino1 is not None
-    ref = F.conv1d(x, w, b, padding=(k - 1) // 2)
+    conv = lambda t: F.conv1d(t, w, b, padding=pad, dilation=d)
+    ref = conv(x)
     xd = dev.t(x)
     ops.gemm_tile = tile
     old_min, ops.winograd1d_min_positions = ops.winograd1d_min_positions, 1
     try:
         if mode == "resblock":      # x + conv(lrelu(x)): one ResBlock1 step
             got = ops.conv(xd, pc, res=xd, pre_act=ops.ACT_LRELU, pre_slope=0.1)
-            ref = F.conv1d(F.leaky_relu(x, 0.1), w, b, padding=(k - 1) // 2) + x
+            ref = conv(F.leaky_relu(x, 0.1)) + x
         elif mode == "accum":       # xs += resblock(x) / 3
             y0, r = torch.randn_like(ref), torch.randn_like(ref)
             got = dev.t(y0.clone())
             ops.conv(xd, pc, res=dev.t(r), out=got, pre_act=ops.ACT_LRELU, pre_slope=0.1, accumulate=True, out_scale=1 / 3)
-            ref = y0 + (F.conv1d(F.leaky_relu(x, 0.1), w, b, padding=(k - 1) // 2) + r) / 3
+            ref = y0 + (conv(F.leaky_relu(x, 0.1)) + r) / 3
         elif mode == "act":
             got, ref = ops.conv(xd, pc, act=ops.ACT_LRELU, act_slope=0.2), F.leaky_relu(ref, 0.2)
         elif mode == "slice":       # input and output are channel slices of wider buffers
@@ -95,6 +97,20 @@ def test_g1w_resblock_layers(dev, tile, k):
     assert _run(dev, 1, 16, 33, k, 8, tile, "plain", seed=k + 2) < 2e-6           # two outputs pairs per lane, one channel stage / two
 
 
+@pytest.mark.parametrize("d", [3, 5])
+@pytest.mark.parametrize("k", [3, 7, 11])
+def test_g1w_dilated_layers(dev, k, d):
+    """Dilations 3 and 5 (the first convolution of the second and third pair of every ResBlock): output pairs (n, n + d), a lane owns the
+    progression n + {0, d, 2 d, 3 d}, 30 of 32 lanes = 120 outputs per wave, the epilogue through an LDS tile.  Maps of several 480-output
+    column tiles with a tail, lengths that are not a multiple of 120, ragged channels, several images, every epilogue mode."""
+    T = 1304 if dev.big else 500
+    assert _run(dev, 1, 64, 64, k, T, 0, "resblock", seed=k + d, d=d) < 2e-6
+    assert _run(dev, 2, 48, 72, k, T - 128, 0, "accum", seed=k + d + 1, d=d) < 2e-6
+    assert _run(dev, 1, 16, 33, k, 8, 0, "plain", seed=k + d + 2, d=d) < 2e-6
+    assert _run(dev, 1, 24, 40, k, 124, 0, "slice", seed=k + d + 3, d=d) < 2e-6
+    assert _run(dev, 1, 17, 8, k, 480, 0, "act", seed=k + d + 4, d=d) < 2e-6
+
+
 @pytest.mark.parametrize("seed", range(20))
 def test_g1w_fuzz(dev, seed):
     rng = random.Random(seed)
@@ -104,18 +120,20 @@ def test_g1w_fuzz(dev, seed):
     k = rng.choice([3, 7, 11])
     T = 4 * rng.choice([1, 3, 16, 64, 65, 97, 130, 257])
     mode = rng.choice(["plain", "act", "accum", "slice"] + (["resblock"] if co == ci else []))
-    tile = rng.choice([0, 2, 3])
-    err = _run(dev, n, ci, co, k, T, tile, mode, seed=seed)
-    assert err < 2e-6, ((n, ci, co, k, T, mode, tile), err)
+    d = rng.choice([1, 1, 3, 5])
+    tile = rng.choice([0, 2, 3]) if d == 1 else 0
+    err = _run(dev, n, ci, co, k, T, tile, mode, seed=seed, d=d)
+    assert err < 2e-6, ((n, ci, co, k, d, T, mode, tile), err)
 
 
 def test_g1w_leaves_other_layers_alone(dev, monkeypatch):
-    """Dilated, strided, k = 5, unaligned or short layers: the direct kernels run (and the f0 models never carry the slot image)."""
+    """Other dilations / paddings, strided, k = 5, unaligned or short layers: the direct kernels run (and the f0 models never carry the slot
+    image)."""
     monkeypatch.setattr(ops, "winograd1d_min_positions", 1)
     torch.manual_seed(1)
     x = torch.randn(1, 32, 256)
     w = torch.randn(64, 32, 3) * 0.2
-    for kw in (dict(padding=3, dilation=3), dict(padding=1, stride=2), dict(padding=0)):
+    for kw in (dict(padding=2, dilation=2), dict(padding=1, dilation=3), dict(padding=1, stride=2), dict(padding=0)):
         y = ops.conv(dev.t(x), ops.PackedConv(w, None, device=dev.device, **kw))
         assert _lib.last_launch() != "conv_g1w_kernel" and rel_rms(y, F.conv1d(x, w, **kw)) < 1e-5
     w5 = torch.randn(64, 32, 5) * 0.2

@@ -9,11 +9,13 @@ dev = torch.device("cuda:0")
 NAMES = {-1: "ws3", 0: "policy", 2: "64x256", 3: "32x512", 5: "32x512s"}
 codes = [int(c) for c in (sys.argv[1] if len(sys.argv) > 1 else "-1,3,5").split(",")]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+dils = [int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "1").split(",")]
 tot = {c: 0.0 for c in codes}
 for c, t in [(256, 73080), (128, 730800), (64, 1461600), (32, 2923200)]:
-    for k in (3, 7, 11):
+  for k in (3, 7, 11):
+    for dil in dils:
         x = torch.randn(1, c, t, device=dev)
-        pc = ops.PackedConv(torch.randn(c, c, k) * 0.03, torch.randn(c), padding=(k - 1) // 2, device=dev)
+        pc = ops.PackedConv(torch.randn(c, c, k) * 0.03, torch.randn(c), padding=(k - 1) // 2 * dil, dilation=dil, device=dev)
         out = torch.empty_like(x)
 
         def fn(code):
@@ -36,11 +38,11 @@ for c, t in [(256, 73080), (128, 730800), (64, 1461600), (32, 2923200)]:
                 e1.record(); torch.cuda.synchronize()
                 times[code].append(e0.elapsed_time(e1) / 3)
         fl = 2.0 * c * c * k * t
-        row = [f"C{c:3d} k{k:2d}"]
+        row = [f"C{c:3d} k{k:2d} d{dil}"]
         for code in codes:
             ms = statistics.median(times[code])
             tot[code] += ms
             row.append(f"{NAMES[code]:7s} {ms*1e3:7.1f} us {fl/ms/1e9:6.1f} TF [{ran[code]}]")
         print(" | ".join(row), flush=True)
 ops.gemm_tile, ops.winograd1d = 0, True
-print("sum over the 12 layers: " + " | ".join(f"{NAMES[c]} {tot[c]:.3f} ms" for c in codes))
+print("sum over the layers: " + " | ".join(f"{NAMES[c]} {tot[c]:.3f} ms" for c in codes))
