@@ -438,7 +438,8 @@ def conv(x, pc, res=None, out=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NON
     wino2 = (wino and winograd2d and getattr(pc, "w_wino2", None) is not None and w % 4 == 0 and x4.stride(0) % 4 == 0 and x4.stride(1) % 4 == 0
              and x4.stride(2) % 4 == 0 and x4.data_ptr() % 16 == 0)
     # the one-dimensional form F(2, 3) of a k = 3 / 7 / 11 layer (csrc/conv_g1w.h): aligned rows of a multiple of four positions
-    wino1 = (winograd1d and getattr(pc, "w_wino1", None) is not None and is1d and not shuffle and out_len is None and w % 4 == 0
+    # (layers of fewer than 16 output channels -- the vocoder's conv_post, 32 -> 1 -- are one HBM pass: the streaming kernels keep them)
+    wino1 = (winograd1d and getattr(pc, "w_wino1", None) is not None and pc.cout >= 16 and is1d and not shuffle and out_len is None and w % 4 == 0
              and n * w >= winograd1d_min_positions and pre_act in (ACT_NONE, ACT_LRELU) and 0.0 <= pre_slope <= 1.0
              and x4.data_ptr() % 16 == 0 and x4.stride(0) % 4 == 0 and x4.stride(1) % 4 == 0 and x4.stride(1) >= w
              and o4.data_ptr() % 16 == 0 and o4.stride(0) % 4 == 0 and o4.stride(1) % 4 == 0
