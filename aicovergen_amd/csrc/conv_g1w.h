@@ -101,28 +101,39 @@ __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1w_kernel(
     // ---- DMA plan.  Weights of unit (stage cs, v): slots sl0 .. sl0 + ns - 1 of the 8-channel block kb = cs CS / 8 + (K == 3 ? v : 0)
     const long wslot_q = (long)(p.Cin_pad >> 3) * 2 * p.Mpad;              // quads of one slot's image
     const BufRsrc wb = make_buf(p.w3, (unsigned)lmin((long)PL::NSLOT * wslot_q * 16, 0x7fffffffL));
+    // per-lane byte offsets of this wave's pieces, computed ONCE (a piece inside the unit pipeline is then M0 + one buffer instruction):
+    // weights -- quad q = piece 64 + lane of [slot][parity][BM] -- relative to the unit's (first slot, 8-channel block); the window --
+    // quad q of [channel][RQ] -- relative to the stage's first channel
+    constexpr int PA = (4 * 2 * BM / 64 + 3) / 4, PB = (NB + 3) / 4;
+    unsigned aoff[PA], boff[PB];
+#pragma unroll
+    for (int e = 0; e < PA; ++e) {
+        const int q = (wave + 4 * e) * 64 + lane;
+        const int sl = q / (2 * BM), rem = q - sl * 2 * BM;
+        const int par = rem / BM, m = rem - par * BM;
+        aoff[e] = m_base + m < p.Mpad ? 16u * (unsigned)(sl * wslot_q + (long)par * p.Mpad + m_base + m) : kBufOob;
+    }
+#pragma unroll
+    for (int e = 0; e < PB; ++e) {
+        const int q = (wave + 4 * e) * 64 + lane;
+        const int row = q / RQ, col = q - row * RQ;
+        const int pos = s0 + 4 * col;
+        boff[e] = (q < BQ && pos >= 0 && pos < p.W) ? 4u * (unsigned)(row * (int)p.x_sc + pos) : kBufOob;   // (W % 4 == 0: whole quads)
+    }
     auto issue_a = [&](int kb, int sl0, int ns, float* abuf) __attribute__((always_inline)) {
-        const int nq = ns * 2 * BM;                       // quads: [slot][parity][BM]
+        const int npiece = ns * 2 * BM / 64;              // [slot][parity][BM] quads in 64-quad pieces
         const unsigned soff = (unsigned)(((long)sl0 * wslot_q + (long)kb * 2 * p.Mpad) * 16);
-        for (int piece = wave; piece * 64 < nq; piece += 4) {
-            const int q = piece * 64 + lane;
-            const int sl = q / (2 * BM), rem = q - sl * 2 * BM;
-            const int par = rem / BM, m = rem - par * BM;
-            const bool ok = q < nq && m_base + m < p.Mpad;
-            w2d_dma16(wb, ok ? 16u * (unsigned)(sl * wslot_q + (long)par * p.Mpad + m_base + m) : kBufOob, soff, abuf + piece * 256, lane);
-        }
+#pragma unroll
+        for (int e = 0; e < PA; ++e)
+            if (wave + 4 * e < npiece) w2d_dma16(wb, aoff[e], soff, abuf + (wave + 4 * e) * 256, lane);
     };
     const float* const ximg = p.x + (long)img * p.x_sn;
     auto issue_b = [&](int cs, float* dst) __attribute__((always_inline)) {
         const long left = (long)(p.Cin_g - cs * PL::CS) * p.x_sc * 4;       // absent channels read 0
         const BufRsrc xb = make_buf(ximg + (long)cs * PL::CS * p.x_sc, (unsigned)lmin(left, 0x7fffffffL));
-        for (int piece = wave; piece < NB; piece += 4) {
-            const int q = piece * 64 + lane;
-            const int row = q / RQ, col = q - row * RQ;
-            const int pos = s0 + 4 * col;
-            const bool ok = q < BQ && pos >= 0 && pos < p.W;               // (W % 4 == 0: a quad is inside the row or outside)
-            w2d_dma16(xb, ok ? 4u * (unsigned)(row * (int)p.x_sc + pos) : kBufOob, 0u, dst + piece * 256, lane);
-        }
+#pragma unroll
+        for (int e = 0; e < PB; ++e)
+            if (4 * e + 3 < NB || wave + 4 * e < NB) w2d_dma16(xb, boff[e], 0u, dst + (wave + 4 * e) * 256, lane);
     };
 
     f32x16 M[4][2];                                       // [accumulator set][pair tile]
@@ -273,7 +284,12 @@ __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1w_kernel(
             g1_wait_pieces<0>();   // this wave's pieces of unit u + 1 (and, issued in front of them, the next stage's window)
             lds_barrier();         // unit u + 1 (and, behind a stage's last unit, the next window) is complete; unit u - 1's buffer is free
             if (V == 0 && cs + 1 < nst) issue_b(cs + 1, bbuf + ((cs + 1) & 1) * BSTAGE);
-            if (u + 2 < nunits) issue_unit_a(u + 2, a_fill);
+            if (u + 2 < nunits) {                       // unit u + 2 = (cs + (V + 2) / NU, (V + 2) % NU): known at compile time up to cs
+                constexpr int V2 = (V + 2) % PL::NU;
+                const int cs2 = cs + (V + 2) / PL::NU;
+                if constexpr (K == 3) issue_a(cs2 * 2 + V2, 0, 4, a_fill);
+                else issue_a(cs2, 4 * V2, PL::slots_of(V2), a_fill);
+            }
             load_a(GNT{}, a_nxt, an);
         }
         // k-steps 2 and 3
