@@ -151,13 +151,17 @@ __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1w_kernel(
     const int n_lane = 4 * D * (la / D) + la % D;
     const int f_lane = half * RQ * 4 + wn * PL::SPAN + n_lane + PL::DELTA;
     const float pre_slope = p.pre_slope;
-    // lrelu(v) = max(v, slope v) for 0 <= slope <= 1, as ONE v_med3_f32 behind the multiply: fmaxf() would add a canonicalising v_max(x, x)
-    // per value (IEEE maxnum quiets signalling NaNs); med3(a, b, +inf) = max(a, b) for non-NaN operands, same bits
+    // lrelu(v) = max(v, slope v) for 0 <= slope <= 1: a multiply and ONE v_max_f32 (inline asm: fmaxf() -- and fmed3(a, b, inf), which LLVM
+    // folds back into maxnum -- adds a canonicalising v_max(x, x) per value; same bits for every non-NaN v)
     auto lrelu = [&](float v) __attribute__((always_inline)) {
+        if constexpr (!PRE) return v;
 #ifdef AICG_EMULATED
-        return PRE ? fmaxf(v, v * pre_slope) : v;
+        return fmaxf(v, v * pre_slope);
 #else
-        return PRE ? __builtin_amdgcn_fmed3f(v, v * pre_slope, __builtin_inff()) : v;
+        const float sv = v * pre_slope;
+        float r;
+        asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(sv));
+        return r;
 #endif
     };
 

@@ -306,19 +306,21 @@ class _SynthesizerBase:
                             src = c1
                             inp = y
                         else:
-                            ops.conv(y, c1, out=tmp, pre_act=ops.ACT_LRELU, pre_slope=LRELU_SLOPE)
+                            # c2 reads c1's output only through the leaky ReLU (modules.py:305-309): c1's epilogue applies it once per
+                            # element (same multiplication, same bits) and c2 runs without an input activation
+                            ops.conv(y, c1, out=tmp, pre_act=ops.ACT_LRELU, pre_slope=LRELU_SLOPE, act=ops.ACT_LRELU, act_slope=LRELU_SLOPE)
                             src, inp = c2, tmp
                         if last:  # xs += resblock(x); x = xs / num_kernels  (models.py:506-512)
                             if streams and prev_acc is not None:
                                 st.wait_event(prev_acc)
-                            ops.conv(inp, src, res=y, out=acc, pre_act=ops.ACT_LRELU, pre_slope=LRELU_SLOPE, out_scale=1.0 / nk,
-                                     accumulate=j > 0)
+                            pre = ops.ACT_NONE if c2 is not None else ops.ACT_LRELU
+                            ops.conv(inp, src, res=y, out=acc, pre_act=pre, pre_slope=LRELU_SLOPE, out_scale=1.0 / nk, accumulate=j > 0)
                             if streams:
                                 prev_acc = torch.cuda.Event()
                                 prev_acc.record(st)
                         else:
                             dst = ya if y is not ya else yb
-                            ops.conv(inp, src, res=y, out=dst, pre_act=ops.ACT_LRELU, pre_slope=LRELU_SLOPE)
+                            ops.conv(inp, src, res=y, out=dst, pre_act=ops.ACT_NONE if c2 is not None else ops.ACT_LRELU, pre_slope=LRELU_SLOPE)
                             y = dst
             if streams:
                 main.wait_event(prev_acc)
