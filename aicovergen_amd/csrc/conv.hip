@@ -155,9 +155,9 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
     if (d->wino == 8) {
         // one-dimensional Winograd F(2, 3) of a k = 3 / 7 / 11, dilation-1 layer (conv_g1w.h): w_packed is the image pair of the
         // (Cout, Cin, 1, S) slot kernel, S = 4 / 10 / 15 (ops.winograd1d_kernel)
-        if (!d->packed_v3 || (p.KW != 3 && p.KW != 7 && p.KW != 11))
-            return fail(AICG_E_ARG, "aicg_conv_forward: wino 8 needs a packed k = 3 / 7 / 11 one-dimensional layer");
-        const int nslot = p.KW == 3 ? 4 : p.KW == 7 ? 10 : 15;
+        if (!d->packed_v3 || (p.KW != 3 && p.KW != 5 && p.KW != 7 && p.KW != 11))
+            return fail(AICG_E_ARG, "aicg_conv_forward: wino 8 needs a packed k = 3 / 5 / 7 / 11 one-dimensional layer");
+        const int nslot = p.KW == 3 ? 4 : p.KW == 5 ? 7 : p.KW == 7 ? 10 : 15;
         p.w3 = w_packed + (long)nslot * p.Cin_pad * p.Mpad;
         if (!conv_g1w_applicable(p, pad_w_end))
             return fail(AICG_E_ARG, "aicg_conv_forward: wino 8 needs stride 1, dilation 1 / 3 / 5, same padding, one group, W %% 4 == 0, 16-byte aligned "

@@ -35,7 +35,7 @@ namespace aicg {
 
 template <int K, int D = 1>
 struct G1wPlan {
-    static_assert(K == 3 || K == 7 || K == 11, "kernel sizes of the vocoder's ResBlocks");
+    static_assert(K == 3 || K == 5 || K == 7 || K == 11, "kernel sizes of the vocoder's ResBlocks (3, 7, 11) and of the flow's WaveNet layers (5)");
     static_assert(D == 1 || D == 3 || D == 5, "dilations of the vocoder's ResBlocks");
     static constexpr int P = (K - 1) / 2;
     static constexpr int NFULL = K / 3, REM = K % 3;            // 3-tap groups, remainder taps
@@ -400,7 +400,8 @@ __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1w_kernel(
 inline bool conv_g1w_applicable(const ConvArgs& p, int pad_w_end) {
     auto al = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     auto m4 = [](long v) { return (v & 3) == 0; };
-    if (p.KH != 1 || p.H != 1 || p.Ho != 1 || (p.KW != 3 && p.KW != 7 && p.KW != 11) || p.groups != 1 || p.sw != 1 || !p.w3) return false;
+    if (p.KH != 1 || p.H != 1 || p.Ho != 1 || (p.KW != 3 && p.KW != 5 && p.KW != 7 && p.KW != 11) || p.groups != 1 || p.sw != 1 || !p.w3) return false;
+    if (p.KW == 5 && p.dw != 1) return false;
     if (p.dw != 1 && p.dw != 3 && p.dw != 5) return false;
     if (p.pw != (p.KW - 1) / 2 * p.dw || pad_w_end != p.pw || p.ph || p.Wo != p.W || (p.W & 3) || p.Cin_g < 16) return false;
     if (p.pre_act != AICG_ACT_NONE && !(p.pre_act == AICG_ACT_LRELU && p.pre_slope >= 0.f && p.pre_slope <= 1.f)) return false;
@@ -431,6 +432,7 @@ template <int WM, int WN, int WPS, int SCH = 0, bool DIL = true>
 static int launch_conv_g1w(ConvArgs& p, hipStream_t stream) {
     if (p.dw == 1) {
         if (p.KW == 3) return launch_conv_g1w_kd<3, 1, WM, WN, WPS, SCH>(p, stream);
+        if (p.KW == 5) return launch_conv_g1w_kd<5, 1, WM, WN, WPS, SCH>(p, stream);
         if (p.KW == 7) return launch_conv_g1w_kd<7, 1, WM, WN, WPS, SCH>(p, stream);
         return launch_conv_g1w_kd<11, 1, WM, WN, WPS, SCH>(p, stream);
     }

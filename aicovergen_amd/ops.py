@@ -258,7 +258,7 @@ def winograd2d_image(w, quads=False):
 # per output pair and input channel instead of 6 / 14 / 22.  Layers packed while this is set carry the slot image next to the direct one;
 # conv() takes it where the kernel applies (aligned rows, W % 4 == 0, enough positions).  The f0 models never do (fp32_layers()).
 winograd1d = os.environ.get("AICG_WINOGRAD1D", "1") != "0"
-winograd1d_min_positions = 16384
+winograd1d_min_positions = int(os.environ.get("AICG_WINOGRAD1D_MIN", "16384"))
 
 
 def winograd1d_kernel(w):
@@ -266,7 +266,7 @@ def winograd1d_kernel(w):
     the four F(2, 3) weights (g0, (g0 + g1 + g2) / 2, (g0 - g1 + g2) / 2, g2); a remainder of two taps (a, b): (a, a + b, b); one tap a:
     (a, -a).  Sums in float64, rounded once."""
     k = w.shape[-1]
-    assert k in (3, 7, 11)
+    assert k in (3, 5, 7, 11)
     wd = w.detach().double()
     slots = []
     for g in range(k // 3):
@@ -303,8 +303,8 @@ class PackedConv:
         self.w = pack_conv_weight(weight.to(device), groups, self.split)
         self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
         self.w_wino = self.w_wino2 = self.w_wino2q = self.w_wino1 = None
-        if (winograd1d and not self.split and not _fp32_depth and self.kh == 1 and self.kw in (3, 7, 11) and stride == (1, 1)
-                and dilation[1] in (1, 3, 5) and padding == (0, (self.kw - 1) // 2 * dilation[1]) and self.padding_end is None
+        if (winograd1d and not self.split and not _fp32_depth and self.kh == 1 and self.kw in (3, 5, 7, 11) and stride == (1, 1)
+                and dilation[1] in ((1, 3, 5) if self.kw != 5 else (1,)) and padding == (0, (self.kw - 1) // 2 * dilation[1]) and self.padding_end is None
                 and groups == 1 and cin_g >= 16):
             # slot image of the 1-D Winograd form, packed like any k-tap kernel (slots in the taps' place)
             self.w_wino1 = pack_conv_weight(winograd1d_kernel(weight.detach().to(device=device, dtype=torch.float32)[:, :, 0]).unsqueeze(2), 1, False)

@@ -17,7 +17,7 @@ from conftest import rel_rms
 def test_slot_kernel_reproduces_the_direct_form():
     """ops.winograd1d_kernel in float64 arithmetic: Y = A^T [sum_slots U (.) V] equals the direct k-tap sum for k = 3, 7, 11."""
     torch.manual_seed(0)
-    for k in (3, 7, 11):
+    for k in (3, 5, 7, 11):
         w = torch.randn(2, 3, k, dtype=torch.float64)
         u = ops.winograd1d_kernel(w.float()).double()          # (2, 3, S), rounded to fp32 once
         x = torch.randn(3, 40, dtype=torch.float64)
@@ -88,7 +88,7 @@ def _run(dev, n, ci, co, k, T, tile, mode, seed=0, expect="conv_g1w_kernel", d=1
 
 
 @pytest.mark.parametrize("tile", [0, 2, 3])
-@pytest.mark.parametrize("k", [3, 7, 11])
+@pytest.mark.parametrize("k", [3, 5, 7, 11])
 def test_g1w_resblock_layers(dev, tile, k):
     T = 1304 if dev.big else 392
     co = 32 if tile == 3 else 64
@@ -117,10 +117,10 @@ def test_g1w_fuzz(dev, seed):
     n = rng.choice([1, 1, 2])
     ci = rng.choice([16, 24, 40, 64, 100, 130])
     co = rng.choice([16, 32, 33, 40, 64, 128, 200])
-    k = rng.choice([3, 7, 11])
+    k = rng.choice([3, 5, 7, 11])
     T = 4 * rng.choice([1, 3, 16, 64, 65, 97, 130, 257])
     mode = rng.choice(["plain", "act", "accum", "slice"] + (["resblock"] if co == ci else []))
-    d = rng.choice([1, 1, 3, 5])
+    d = rng.choice([1, 1, 3, 5]) if k != 5 else 1
     tile = rng.choice([0, 2, 3]) if d == 1 else 0
     err = _run(dev, n, ci, co, k, T, tile, mode, seed=seed, d=d)
     assert err < 2e-6, ((n, ci, co, k, d, T, mode, tile), err)
@@ -136,9 +136,9 @@ def test_g1w_leaves_other_layers_alone(dev, monkeypatch):
     for kw in (dict(padding=2, dilation=2), dict(padding=1, dilation=3), dict(padding=1, stride=2), dict(padding=0)):
         y = ops.conv(dev.t(x), ops.PackedConv(w, None, device=dev.device, **kw))
         assert _lib.last_launch() != "conv_g1w_kernel" and rel_rms(y, F.conv1d(x, w, **kw)) < 1e-5
-    w5 = torch.randn(64, 32, 5) * 0.2
-    y = ops.conv(dev.t(x), ops.PackedConv(w5, None, padding=2, device=dev.device))
-    assert _lib.last_launch() != "conv_g1w_kernel" and rel_rms(y, F.conv1d(x, w5, padding=2)) < 1e-5
+    w9 = torch.randn(64, 32, 9) * 0.2
+    y = ops.conv(dev.t(x), ops.PackedConv(w9, None, padding=4, device=dev.device))
+    assert _lib.last_launch() != "conv_g1w_kernel" and rel_rms(y, F.conv1d(x, w9, padding=4)) < 1e-5
     x2 = torch.randn(1, 32, 258)                                   # 258 % 4 != 0
     y = ops.conv(dev.t(x2), ops.PackedConv(w, None, padding=1, device=dev.device))
     assert _lib.last_launch() != "conv_g1w_kernel" and rel_rms(y, F.conv1d(x2, w, padding=1)) < 1e-5
