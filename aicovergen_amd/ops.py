@@ -348,7 +348,7 @@ class ConvProfile:
     def __init__(self):
         self.events = []
         self.flops = 0.0
-        self.flops_executed = 0.0  # what the matrix pipe was given: the Winograd form spends 12 instead of 18 MACs per output pair
+        self.flops_executed = 0.0  # what the matrix pipe was given (the Winograd forms execute fewer multiply-adds than the direct form)
         self.bytes = 0.0  # algorithmic HBM bytes: input + packed weights + output (+ residual / accumulate reads), each once
         self.launches = 0
         self.shapes = []  # per launch: (shape key, flops) -- by_shape() groups them
@@ -456,13 +456,18 @@ def conv(x, pc, res=None, out=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NON
         e1.record()
         prof.events.append((e0, e1))
         prof.flops += 2.0 * n * pc.cout * (pc.cin // pc.groups) * pc.kh * pc.kw * ho * wo
-        prof.flops_executed += 2.0 * n * pc.cout * (pc.cin // pc.groups) * pc.kh * pc.kw * ho * wo * (4.0 / 9.0 if wino2 else 2.0 / 3.0 if wino else 1.0)
+        # what the matrix pipe is given: F(2 x 2, 3 x 3) 16 of 36 multiply-adds, the row form 12 of 18, the 1-D form 4 / 7 / 10 / 15 slots per
+        # output PAIR where the direct form spends 2 k (k = 3 / 5 / 7 / 11) -- times 32 / 30 for the dilated layers' two idle lanes per tile
+        exe = 4.0 / 9.0 if wino2 else 2.0 / 3.0 if wino else 1.0
+        if wino1:
+            exe = {3: 4, 5: 7, 7: 10, 11: 15}[pc.kw] / (2.0 * pc.kw) * (1.0 if pc.dilation[1] == 1 else 32.0 / 30.0)
+        prof.flops_executed += 2.0 * n * pc.cout * (pc.cin // pc.groups) * pc.kh * pc.kw * ho * wo * exe
         prof.bytes += 4.0 * (n * c * h * w + pc.cout * (pc.cin // pc.groups) * pc.kh * pc.kw
                              + n * pc.cout * ho * wo * (1 + (r4 is not None) + bool(accumulate)))
         prof.launches += 1
         prof.shapes.append(("N%d C%d>%d %dx%d k%dx%d s%d,%d d%d,%d g%d%s%s%s" % (
             n, c, pc.cout, h, w, pc.kh, pc.kw, pc.stride[0], pc.stride[1], pc.dilation[0], pc.dilation[1], pc.groups,
-            " res" if r4 is not None else "", " acc" if accumulate else "", (" shuf" if shuffle else "") + (" wino2" if wino2 else " wino" if wino else "")),
+            " res" if r4 is not None else "", " acc" if accumulate else "", (" shuf" if shuffle else "") + (" wino2" if wino2 else " wino" if wino else " wino1d" if wino1 else "")),
             2.0 * n * pc.cout * (pc.cin // pc.groups) * pc.kh * pc.kw * ho * wo))
     return out
 

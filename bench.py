@@ -150,7 +150,7 @@ def pmc_traffic_per_launch():
     """HBM bytes per conv launch from the committed rocprofv3 PMC passes of this same command (profiles/r03_summary.json, falling
     back to earlier rounds): FETCH_SIZE (x 2: the gfx950 under-report for wide reads, MI355X_MICROARCH.md) + WRITE_SIZE, KiB units, summed
     over the conv kernels; None when no summary is committed.  The counters cannot be collected inside the timed run."""
-    for tag in ("r04", "r03", "r02", "r01"):
+    for tag in ("r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_summary.json" % tag)
         try:
             s = json.load(open(path))
@@ -413,8 +413,11 @@ def main():
                 "executed": conv["tflops_executed"],
                 "executed_note": "TFLOP/s the matrix pipe was given: the 3x3 TFC layers of MDX-Net run the Winograd F(2x2,3x3) kernel "
                                  "(conv_w2d: 16 instead of 36 multiply-adds per 2x2 output block; AICG_WINOGRAD=1: the F(2,3)-along-rows "
-                                 "kernel conv_ws3w, 2/3); `achieved` counts every layer's direct-form flops, `frac` = executed / peak",
-                "kernel": "conv family (fp32 MFMA: conv_ws3 / conv_ws3m16h implicit GEMM, conv_g1 LDS-DMA staged 1x1 GEMM, conv_w2d Winograd F(2x2,3x3))" if not split_mode
+                                 "kernel conv_ws3w, 2/3), the vocoder's k = 3 / 7 / 11 ResBlock layers the one-dimensional F(2,3) kernel "
+                                 "(conv_g1w: 4 / 10 / 15 instead of 6 / 14 / 22 per output pair); `achieved` counts every layer's "
+                                 "direct-form flops, `frac` = executed / peak",
+                "kernel": "conv family (fp32 MFMA: conv_ws3 / conv_ws3m16h implicit GEMM, conv_g1 / conv_g1s LDS-DMA staged 1x1 and stride-2 GEMMs, "
+                          "conv_w2d Winograd F(2x2,3x3), conv_g1w one-dimensional Winograd F(2,3))" if not split_mode
                 else "conv family (split precision: conv_ws3s on the bf16 MFMA, 3 MFMAs per product -- achieved and peak are "
                      "in fp32-equivalent TFLOP/s, peak = 2516.6 / 3; the f0 models' layers run the fp32 kernels)",
                 "measured": "HIP events around every launch of one extra step of the same work, taken right behind the timed "

@@ -18,8 +18,9 @@ tail -40 $OUT/summary.log
 # the raw kernel_stats of the trace pass rides along; the large per-dispatch CSVs stay on the box
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/summary/${TAG}_rocprofv3_kernel_stats_raw.csv 2>/dev/null
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete
-# the 1x1 GEMM's policy against conv_ws3 on this box (round-robin; the per-tile table is profiles/r04_kbench_g1.txt)
-python tools/kbench_g1.py 1,0 3 > $OUT/kbench_g1_policy.txt 2>&1
+# the round's A/B tables on this box (round-robin): stride-2 extractor layers, the vocoder's 1-D Winograd layers
+python tools/kbench_g1s.py 1,0 5 > $OUT/kbench_g1s_policy.txt 2>&1
+python tools/kbench_g1w.py -1,0 5 1,3,5 > $OUT/kbench_g1w_policy.txt 2>&1
 # the judged bench lines of this round
 python bench.py --conv-shapes $OUT/conv_shapes_c3.json > $OUT/bench_c3_default.json 2> $OUT/bench_c3_default.err
 python bench.py --config C5 --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_c5.json 2>/dev/null

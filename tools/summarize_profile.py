@@ -22,7 +22,7 @@ def find(sub, pat):
 def is_conv(k):
     """the implicit-GEMM convolution family: conv_ws_kernel / conv_ws16_kernel (wave-specialised), conv_mfma_kernel /
     conv_mfma16_kernel (small-problem fallback)"""
-    return k.startswith(("conv_ws_kernel", "conv_ws3_kernel", "conv_ws3s_kernel", "conv_ws3m16_kernel", "conv_ws3m16h_kernel", "conv_ws3w_kernel", "conv_w2d_kernel", "conv_g1_kernel", "conv_ws16_kernel", "conv_mfma_kernel", "conv_mfma16_kernel", "conv_pointwise_kernel"))
+    return k.startswith(("conv_ws_kernel", "conv_ws3_kernel", "conv_ws3s_kernel", "conv_ws3m16_kernel", "conv_ws3m16h_kernel", "conv_ws3w_kernel", "conv_w2d_kernel", "conv_g1_kernel", "conv_g1s_kernel", "conv_g1w_kernel", "conv_ws16_kernel", "conv_mfma_kernel", "conv_mfma16_kernel", "conv_pointwise_kernel"))
 
 
 def short(name):
