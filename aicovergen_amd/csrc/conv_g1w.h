@@ -72,10 +72,14 @@ __device__ __forceinline__ float g1w_w(const float4 (&q)[5]) {        // W[I] ou
 // SCH: the k-step regions carry an explicit interleave -- the next k-step's window reads in front of the first MFMA, its leaky ReLU and
 // B^T d four VALU instructions at a time behind each of the following MFMAs -- instead of [prep][8 MFMAs] blocks (a wave issues in order:
 // left as blocks, the ~25 VALU instructions of a prep sit between two MFMA bursts with this wave's share of the matrix pipe idle).
-template <int K, int D, int WM, int WN, int WPS, bool PRE, int SCH = 0>
+// PERS (d = 1): a workgroup WALKS tiles (blockIdx.x, + gridDim.x, ...): the unit pipeline runs on into the next tile -- its first window
+// and its first two units' weights are issued under the last units of the running tile -- so that only the first tile of a workgroup
+// waits for HBM in its prologue (a tile of a k = 3 layer is 50 us of work behind ~3 us of first-window latency).
+template <int K, int D, int WM, int WN, int WPS, bool PRE, int SCH = 0, bool PERS = false>
 __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1w_kernel(ConvArgs p) {
     using PL = G1wPlan<K, D>;
     static_assert(WM * WN == 4, "four waves");
+    static_assert(!PERS || D == 1, "the dilated epilogue's LDS tiles overlay the pipeline's buffers");
     constexpr int BM = 32 * WM, BN = PL::SPAN * WN;
     constexpr int RQ = g1w_row_quads(BN, K, D);
     constexpr int ASTAGE = 4 * 2 * BM * 4;               // floats: <= 4 slots x 2 parities x BM quads
@@ -89,51 +93,64 @@ __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1w_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l31 = lane & 31;
     const int wm = wave / WN, wn = wave % WN;
-    const int bid = (int)xcd_remap(blockIdx.x, gridDim.x);
-    const int mt = bid % p.tiles_h;
-    const int ct = (bid / p.tiles_h) % p.tiles_w;
-    const int img = bid / (p.tiles_h * p.tiles_w);
-    const int m_base = mt * BM;
-    const int n0 = ct * BN;
+    const int nwg_all = p.N * p.tiles_h * p.tiles_w;     // tiles of the launch (PERS: more than workgroups)
     const int nst = (p.Cin_g + PL::CS - 1) / PL::CS;
-    const int s0 = n0 - 4 * PL::BACK;                    // first position of the window
+    // tile-dependent state: the running tile's and (PERS) the next one's -- coordinates, the image's base, this wave's DMA offsets
+    int m_base, n0, img, s0;
+    const float* ximg;
+    auto coords = [&](int hw) __attribute__((always_inline)) {
+        const int bid = (int)xcd_remap((unsigned)hw, (unsigned)nwg_all);
+        const int mt = bid % p.tiles_h;
+        const int ct = (bid / p.tiles_h) % p.tiles_w;
+        img = bid / (p.tiles_h * p.tiles_w);
+        m_base = mt * BM;
+        n0 = ct * BN;
+        s0 = n0 - 4 * PL::BACK;                          // first position of the window
+        ximg = p.x + (long)img * p.x_sn;
+    };
+    coords((int)blockIdx.x);
 
     // ---- DMA plan.  Weights of unit (stage cs, v): slots sl0 .. sl0 + ns - 1 of the 8-channel block kb = cs CS / 8 + (K == 3 ? v : 0)
     const long wslot_q = (long)(p.Cin_pad >> 3) * 2 * p.Mpad;              // quads of one slot's image
     const BufRsrc wb = make_buf(p.w3, (unsigned)lmin((long)PL::NSLOT * wslot_q * 16, 0x7fffffffL));
-    // per-lane byte offsets of this wave's pieces, computed ONCE (a piece inside the unit pipeline is then M0 + one buffer instruction):
-    // weights -- quad q = piece 64 + lane of [slot][parity][BM] -- relative to the unit's (first slot, 8-channel block); the window --
-    // quad q of [channel][RQ] -- relative to the stage's first channel
+    // per-lane byte offsets of this wave's pieces, computed ONCE per tile (a piece inside the unit pipeline is then M0 + one buffer
+    // instruction): weights -- quad q = piece 64 + lane of [slot][parity][BM] -- relative to the unit's (first slot, 8-channel block); the
+    // window -- quad q of [channel][RQ] -- relative to the stage's first channel
     constexpr int PA = (4 * 2 * BM / 64 + 3) / 4, PB = (NB + 3) / 4;
-    unsigned aoff[PA], boff[PB];
+    unsigned aoff[PA], boff[PB];                          // the running tile's
+    unsigned aoff1[PERS ? PA : 1], boff1[PERS ? PB : 1];  // PERS: the next tile's
+    const float* ximg1 = nullptr;
+    bool has1 = false;
+    auto offsets = [&](unsigned (&ao)[PA], unsigned (&bo)[PB]) __attribute__((always_inline)) {   // from m_base, s0
 #pragma unroll
-    for (int e = 0; e < PA; ++e) {
-        const int q = (wave + 4 * e) * 64 + lane;
-        const int sl = q / (2 * BM), rem = q - sl * 2 * BM;
-        const int par = rem / BM, m = rem - par * BM;
-        aoff[e] = m_base + m < p.Mpad ? 16u * (unsigned)(sl * wslot_q + (long)par * p.Mpad + m_base + m) : kBufOob;
-    }
+        for (int e = 0; e < PA; ++e) {
+            const int q = (wave + 4 * e) * 64 + lane;
+            const int sl = q / (2 * BM), rem = q - sl * 2 * BM;
+            const int par = rem / BM, m = rem - par * BM;
+            ao[e] = m_base + m < p.Mpad ? 16u * (unsigned)(sl * wslot_q + (long)par * p.Mpad + m_base + m) : kBufOob;
+        }
 #pragma unroll
-    for (int e = 0; e < PB; ++e) {
-        const int q = (wave + 4 * e) * 64 + lane;
-        const int row = q / RQ, col = q - row * RQ;
-        const int pos = s0 + 4 * col;
-        boff[e] = (q < BQ && pos >= 0 && pos < p.W) ? 4u * (unsigned)(row * (int)p.x_sc + pos) : kBufOob;   // (W % 4 == 0: whole quads)
-    }
-    auto issue_a = [&](int kb, int sl0, int ns, float* abuf) __attribute__((always_inline)) {
+        for (int e = 0; e < PB; ++e) {
+            const int q = (wave + 4 * e) * 64 + lane;
+            const int row = q / RQ, col = q - row * RQ;
+            const int pos = s0 + 4 * col;
+            bo[e] = (q < BQ && pos >= 0 && pos < p.W) ? 4u * (unsigned)(row * (int)p.x_sc + pos) : kBufOob;   // (W % 4 == 0: whole quads)
+        }
+    };
+    offsets(aoff, boff);
+    auto issue_a = [&](const unsigned (&ao)[PA], int kb, int sl0, int ns, float* abuf) __attribute__((always_inline)) {
         const int npiece = ns * 2 * BM / 64;              // [slot][parity][BM] quads in 64-quad pieces
         const unsigned soff = (unsigned)(((long)sl0 * wslot_q + (long)kb * 2 * p.Mpad) * 16);
 #pragma unroll
         for (int e = 0; e < PA; ++e)
-            if (wave + 4 * e < npiece) w2d_dma16(wb, aoff[e], soff, abuf + (wave + 4 * e) * 256, lane);
+            if (wave + 4 * e < npiece) w2d_dma16(wb, ao[e], soff, abuf + (wave + 4 * e) * 256, lane);
     };
-    const float* const ximg = p.x + (long)img * p.x_sn;
-    auto issue_b = [&](int cs, float* dst) __attribute__((always_inline)) {
+    auto issue_b = [&](const unsigned (&bo)[PB], const float* xi, int cs, float* dst) __attribute__((always_inline)) {
         const long left = (long)(p.Cin_g - cs * PL::CS) * p.x_sc * 4;       // absent channels read 0
-        const BufRsrc xb = make_buf(ximg + (long)cs * PL::CS * p.x_sc, (unsigned)lmin(left, 0x7fffffffL));
+        const BufRsrc xb = make_buf(xi + (long)cs * PL::CS * p.x_sc, (unsigned)lmin(left, 0x7fffffffL));
 #pragma unroll
         for (int e = 0; e < PB; ++e)
-            if (4 * e + 3 < NB || wave + 4 * e < NB) w2d_dma16(xb, boff[e], 0u, dst + (wave + 4 * e) * 256, lane);
+            if (4 * e + 3 < NB || wave + 4 * e < NB) w2d_dma16(xb, bo[e], 0u, dst + (wave + 4 * e) * 256, lane);
     };
 
     f32x16 M[4][2];                                       // [accumulator set][pair tile]
@@ -230,36 +247,43 @@ __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1w_kernel(
         }
     };
 
-    // ---- the unit pipeline.  Unit index u = cs NU + v; weights ring a[u % 3], window bbuf[cs & 1].
-    auto issue_unit_a = [&](int u, float* abuf) __attribute__((always_inline)) {
-        const int cs = u / PL::NU, v = u - cs * PL::NU;
-        if constexpr (K == 3) issue_a(cs * 2 + v, 0, 4, abuf);
-        else issue_a(cs, 4 * v, v < PL::NFULL ? 4 : PL::slots_of(PL::NFULL), abuf);
-    };
+    // ---- the unit pipeline.  Unit index u = cs NU + v; weights ring of three (rotating per unit, across tiles), windows bbuf[wpar] (the
+    // running stage's) and bbuf[wpar ^ 1] (the next stage's -- the next TILE's first one behind a tile's last stage when PERS).
     const int nunits = nst * PL::NU;
     float* a_cur = smem;
     float* a_nxt = smem + ASTAGE;
     float* a_fill = smem + 2 * ASTAGE;
-    issue_b(0, bbuf);
-    issue_unit_a(0, a_cur);
-    if (nunits > 1) issue_unit_a(1, a_nxt);
+    int wpar = 0;
+    auto issue_unit = [&](const unsigned (&ao)[PA], int cs, int v, float* abuf) __attribute__((always_inline)) {
+        if constexpr (K == 3) issue_a(ao, cs * 2 + v, 0, 4, abuf);
+        else issue_a(ao, cs, 4 * v, v < PL::NFULL ? 4 : PL::slots_of(PL::NFULL), abuf);
+    };
+    issue_b(boff, ximg, 0, bbuf);
+    issue_unit(aoff, 0, 0, a_cur);
+    issue_unit(aoff, 1 / PL::NU, 1 % PL::NU, a_nxt);      // (NU >= 2: unit 1 exists)
     g1_wait_pieces<0>();
     lds_barrier();
     float4 af[4], an[4];                                  // A fragments of the running unit / of the next one
     float Vc[2][4], Vn[2][4];                             // operands of the running k-step / of the next one
-    load_a(std::integral_constant<int, 0>{}, a_cur, af);
-    prep(std::integral_constant<int, 0>{}, 0, bbuf, 0, Vc);
-    // one unit of the walk; V (unit inside the stage) and LASTU (the walk's last unit: nothing behind it) at compile time
-    auto run_unit = [&](auto v_tag, auto last_tag, int cs, int u) __attribute__((always_inline)) {
+    auto open_tile = [&]() __attribute__((always_inline)) {   // operands of a tile's first k-step, with nothing to hide behind
+        load_a(std::integral_constant<int, 0>{}, a_cur, af);
+        prep(std::integral_constant<int, 0>{}, 0, bbuf + wpar * BSTAGE, 0, Vc);
+    };
+    open_tile();
+    // One unit of the walk; V (unit inside the stage) at compile time.  MODE 0: a unit with a successor in the same tile (the next unit's
+    // operands are prefetched into registers under this one's last k-steps); 1: a tile's last unit with another tile behind it (PERS: the
+    // barrier and the DMA issue go on, the register prefetch does not -- the epilogue in between needs the registers); 2: the walk's last.
+    auto run_unit = [&](auto v_tag, auto mode_tag, int cs) __attribute__((always_inline)) {
         constexpr int V = decltype(v_tag)::value;
-        constexpr bool LASTU = decltype(last_tag)::value;
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr bool PREF = MODE == 0, SYNC = MODE != 2;
         constexpr int G = K == 3 ? 0 : V;
         constexpr int VN = (V + 1) % PL::NU, GN = K == 3 ? 0 : VN;      // the unit behind this one
         using GT = std::integral_constant<int, G>;
         using GNT = std::integral_constant<int, GN>;
         const int rb = K == 3 ? 8 * V : 0, rbn = K == 3 ? 8 * VN : 0;
-        const float* wbuf = bbuf + (cs & 1) * BSTAGE;
-        const float* wnxt = bbuf + ((V + 1 == PL::NU ? cs + 1 : cs) & 1) * BSTAGE;
+        const float* wbuf = bbuf + wpar * BSTAGE;
+        const float* wnxt = bbuf + (V + 1 == PL::NU ? wpar ^ 1 : wpar) * BSTAGE;
         // (a k-step region: prep of the next k-step + the MFMAs of this one, interleaved when SCH)
         auto interleave = [&]() __attribute__((always_inline)) {
             if constexpr (SCH != 0) {
@@ -284,17 +308,20 @@ __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1w_kernel(
         mma(GT{}, 1, af, Vn);
         interleave();
         w2d_fence();
-        if constexpr (!LASTU) {
+        if constexpr (SYNC) {
             g1_wait_pieces<0>();   // this wave's pieces of unit u + 1 (and, issued in front of them, the next stage's window)
             lds_barrier();         // unit u + 1 (and, behind a stage's last unit, the next window) is complete; unit u - 1's buffer is free
-            if (V == 0 && cs + 1 < nst) issue_b(cs + 1, bbuf + ((cs + 1) & 1) * BSTAGE);
-            if (u + 2 < nunits) {                       // unit u + 2 = (cs + (V + 2) / NU, (V + 2) % NU): known at compile time up to cs
+            if constexpr (V == 0) {
+                if (cs + 1 < nst) issue_b(boff, ximg, cs + 1, bbuf + (wpar ^ 1) * BSTAGE);
+                else if constexpr (PERS) { if (has1) issue_b(boff1, ximg1, 0, bbuf + (wpar ^ 1) * BSTAGE); }
+            }
+            {   // unit u + 2 = (cs + (V + 2) / NU, (V + 2) % NU): known at compile time up to cs; behind the tile's end: the next tile's
                 constexpr int V2 = (V + 2) % PL::NU;
                 const int cs2 = cs + (V + 2) / PL::NU;
-                if constexpr (K == 3) issue_a(cs2 * 2 + V2, 0, 4, a_fill);
-                else issue_a(cs2, 4 * V2, PL::slots_of(V2), a_fill);
+                if (cs2 < nst) issue_unit(aoff, cs2, V2, a_fill);
+                else if constexpr (PERS) { if (has1) issue_unit(aoff1, cs2 - nst, V2, a_fill); }
             }
-            load_a(GNT{}, a_nxt, an);
+            if constexpr (PREF) load_a(GNT{}, a_nxt, an);
         }
         // k-steps 2 and 3
         w2d_fence();
@@ -303,39 +330,40 @@ __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1w_kernel(
         mma(GT{}, 2, af, Vc);
         interleave();
         w2d_fence();
-        if constexpr (!LASTU) prep(GNT{}, 0, wnxt, rbn, Vc);
+        if constexpr (PREF) prep(GNT{}, 0, wnxt, rbn, Vc);
         if constexpr (SCH == 0) w2d_fence();
         mma(GT{}, 3, af, Vn);
-        if constexpr (!LASTU) interleave();
+        if constexpr (PREF) interleave();
         w2d_fence();
-        if constexpr (!LASTU) {
+        if constexpr (PREF) {
 #pragma unroll
             for (int sl = 0; sl < 4; ++sl) af[sl] = an[sl];
         }
         float* t = a_cur; a_cur = a_nxt; a_nxt = a_fill; a_fill = t;
+        if constexpr (V + 1 == PL::NU) wpar ^= 1;
     };
-    using F = std::false_type;
-    using T = std::true_type;
-    for (int cs = 0; cs + 1 < nst; ++cs) {
-        const int u0 = cs * PL::NU;
-        run_unit(std::integral_constant<int, 0>{}, F{}, cs, u0);
-        if constexpr (PL::NU > 1) run_unit(std::integral_constant<int, 1>{}, F{}, cs, u0 + 1);
-        if constexpr (PL::NU > 2) run_unit(std::integral_constant<int, 2>{}, F{}, cs, u0 + 2);
-        if constexpr (PL::NU > 3) run_unit(std::integral_constant<int, 3>{}, F{}, cs, u0 + 3);
-    }
-    {   // the last stage, peeled: its last unit has nothing behind it
-        const int cs = nst - 1, u0 = cs * PL::NU;
-        if constexpr (PL::NU == 1) run_unit(std::integral_constant<int, 0>{}, T{}, cs, u0);
-        if constexpr (PL::NU == 2) { run_unit(std::integral_constant<int, 0>{}, F{}, cs, u0); run_unit(std::integral_constant<int, 1>{}, T{}, cs, u0 + 1); }
+    using M0 = std::integral_constant<int, 0>;
+    // the units of one tile; END = the mode of its last unit
+    auto run_tile = [&](auto end_tag) __attribute__((always_inline)) {
+        using END = decltype(end_tag);
+        for (int cs = 0; cs + 1 < nst; ++cs) {
+            run_unit(std::integral_constant<int, 0>{}, M0{}, cs);
+            if constexpr (PL::NU > 1) run_unit(std::integral_constant<int, 1>{}, M0{}, cs);
+            if constexpr (PL::NU > 2) run_unit(std::integral_constant<int, 2>{}, M0{}, cs);
+            if constexpr (PL::NU > 3) run_unit(std::integral_constant<int, 3>{}, M0{}, cs);
+        }
+        const int cs = nst - 1;   // the last stage, peeled: its last unit ends the tile
+        if constexpr (PL::NU == 2) { run_unit(std::integral_constant<int, 0>{}, M0{}, cs); run_unit(std::integral_constant<int, 1>{}, END{}, cs); }
         if constexpr (PL::NU == 3) {
-            run_unit(std::integral_constant<int, 0>{}, F{}, cs, u0); run_unit(std::integral_constant<int, 1>{}, F{}, cs, u0 + 1);
-            run_unit(std::integral_constant<int, 2>{}, T{}, cs, u0 + 2);
+            run_unit(std::integral_constant<int, 0>{}, M0{}, cs); run_unit(std::integral_constant<int, 1>{}, M0{}, cs);
+            run_unit(std::integral_constant<int, 2>{}, END{}, cs);
         }
         if constexpr (PL::NU == 4) {
-            run_unit(std::integral_constant<int, 0>{}, F{}, cs, u0); run_unit(std::integral_constant<int, 1>{}, F{}, cs, u0 + 1);
-            run_unit(std::integral_constant<int, 2>{}, F{}, cs, u0 + 2); run_unit(std::integral_constant<int, 3>{}, T{}, cs, u0 + 3);
+            run_unit(std::integral_constant<int, 0>{}, M0{}, cs); run_unit(std::integral_constant<int, 1>{}, M0{}, cs);
+            run_unit(std::integral_constant<int, 2>{}, M0{}, cs); run_unit(std::integral_constant<int, 3>{}, END{}, cs);
         }
-    }
+    };
+    auto epilogue = [&]() __attribute__((always_inline)) {
     // ---- A^T: the lane's four outputs per row
     f32x16 y[1][4];
 #pragma unroll
@@ -394,6 +422,47 @@ __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1w_kernel(
         else if (p.act == AICG_ACT_LRELU) body(std::integral_constant<int, 2>{});
         else body(std::integral_constant<int, 3>{});
     }
+    };
+    if constexpr (!PERS) {
+        run_tile(std::integral_constant<int, 2>{});
+        epilogue();
+    } else {
+        // the walk: tile k of this workgroup is tile blockIdx.x + k gridDim.x of the launch; `has1` = the tile behind the running one
+        int hw = (int)blockIdx.x + (int)gridDim.x;
+        auto place_next = [&]() __attribute__((always_inline)) {
+            has1 = hw < nwg_all;
+            if (has1) {
+                const int mb = m_base, nn = n0, im = img, ss = s0;
+                const float* xi = ximg;
+                coords(hw);
+                offsets(aoff1, boff1);
+                ximg1 = ximg;
+                m_base = mb; n0 = nn; img = im; s0 = ss; ximg = xi;
+            }
+            hw += (int)gridDim.x;
+        };
+        place_next();
+        while (true) {
+            if (has1) run_tile(std::integral_constant<int, 1>{});
+            else run_tile(std::integral_constant<int, 2>{});
+            epilogue();
+            if (!has1) break;
+            // the next tile becomes the running one: its first window and its units 0 / 1 are in flight or landed already
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) M[q][j][r] = 0.f;
+            coords(hw - (int)gridDim.x);
+#pragma unroll
+            for (int e = 0; e < PA; ++e) aoff[e] = aoff1[e];
+#pragma unroll
+            for (int e = 0; e < PB; ++e) boff[e] = boff1[e];
+            place_next();
+            open_tile();
+        }
+    }
 }
 
 // host side: a 1-D layer of the form this kernel takes
@@ -411,7 +480,7 @@ inline bool conv_g1w_applicable(const ConvArgs& p, int pad_w_end) {
     return true;
 }
 
-template <int K, int D, int WM, int WN, int WPS, int SCH>
+template <int K, int D, int WM, int WN, int WPS, int SCH, bool PERS = false>
 static int launch_conv_g1w_kd(ConvArgs& p, hipStream_t stream) {
     using PL = G1wPlan<K, D>;
     constexpr int BM = 32 * WM, BN = PL::SPAN * WN;
@@ -422,19 +491,22 @@ static int launch_conv_g1w_kd(ConvArgs& p, hipStream_t stream) {
     size_t lds = (size_t)(3 * 4 * 2 * BM * 4 + 2 * ((PL::CS * g1w_row_quads(BN, K, D) + 63) / 64) * 256) * sizeof(float);
     if (D > 1 && lds < (size_t)4 * 32 * (PL::SPAN + 4) * sizeof(float)) lds = (size_t)4 * 32 * (PL::SPAN + 4) * sizeof(float);   // the epilogue's tiles
     if (lds > 160 * 1024) return 1;
-    auto kern = p.pre_act != AICG_ACT_NONE ? conv_g1w_kernel<K, D, WM, WN, WPS, true, SCH> : conv_g1w_kernel<K, D, WM, WN, WPS, false, SCH>;
+    auto kern = p.pre_act != AICG_ACT_NONE ? conv_g1w_kernel<K, D, WM, WN, WPS, true, SCH, PERS> : conv_g1w_kernel<K, D, WM, WN, WPS, false, SCH, PERS>;
     allow_dynamic_lds((const void*)kern, lds);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, stream, p);
+    long grid = nwg;
+    const long slots = p.dbg > 0 ? p.dbg : 2 * 256;      // two workgroups per CU, each walking tiles blockIdx.x, + grid, ... (p.dbg: tests)
+    if (PERS && nwg > slots) grid = slots;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, stream, p);
     return check_launch("conv_g1w_kernel");
 }
 
-template <int WM, int WN, int WPS, int SCH = 0, bool DIL = true>
+template <int WM, int WN, int WPS, int SCH = 0, bool DIL = true, bool PERS = false>
 static int launch_conv_g1w(ConvArgs& p, hipStream_t stream) {
     if (p.dw == 1) {
-        if (p.KW == 3) return launch_conv_g1w_kd<3, 1, WM, WN, WPS, SCH>(p, stream);
-        if (p.KW == 5) return launch_conv_g1w_kd<5, 1, WM, WN, WPS, SCH>(p, stream);
-        if (p.KW == 7) return launch_conv_g1w_kd<7, 1, WM, WN, WPS, SCH>(p, stream);
-        return launch_conv_g1w_kd<11, 1, WM, WN, WPS, SCH>(p, stream);
+        if (p.KW == 3) return launch_conv_g1w_kd<3, 1, WM, WN, WPS, SCH, PERS>(p, stream);
+        if (p.KW == 5) return launch_conv_g1w_kd<5, 1, WM, WN, WPS, SCH, PERS>(p, stream);
+        if (p.KW == 7) return launch_conv_g1w_kd<7, 1, WM, WN, WPS, SCH, PERS>(p, stream);
+        return launch_conv_g1w_kd<11, 1, WM, WN, WPS, SCH, PERS>(p, stream);
     }
     if constexpr (DIL) {
         if (p.dw == 3) {
@@ -453,5 +525,6 @@ static int launch_conv_g1w(ConvArgs& p, hipStream_t stream) {
 int run_g1w_64x256(ConvArgs& p, hipStream_t st);    // 2 x 2 waves of 32 rows x 128 outputs
 int run_g1w_32x512(ConvArgs& p, hipStream_t st);    // 1 x 4 waves: all four share the tile's 32 rows
 int run_g1w_32x512_sched(ConvArgs& p, hipStream_t st);   // ... with the explicit MFMA / VALU interleave (SCH)
+int run_g1w_32x512_pers(ConvArgs& p, hipStream_t st);    // ... as a persistent tile walk (d = 1)
 
 }  // namespace aicg

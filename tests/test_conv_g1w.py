@@ -97,6 +97,20 @@ def test_g1w_resblock_layers(dev, tile, k):
     assert _run(dev, 1, 16, 33, k, 8, tile, "plain", seed=k + 2) < 2e-6           # two outputs pairs per lane, one channel stage / two
 
 
+@pytest.mark.parametrize("k", [3, 5, 7, 11])
+def test_g1w_persistent_tile_walk(dev, k):
+    """The persistent form (aicg_conv_desc.gemm_tile 6; 7 = the same walk on three workgroups): a workgroup takes tiles blockIdx.x,
+    + gridDim.x, ... with the unit pipeline running on into the next tile.  Maps of 5-11 tiles over three workgroups (uneven: some walk
+    four tiles, some three), two M tiles, several images, every epilogue mode; and the launch form whose grid covers all tiles."""
+    T = 2304 if dev.big else 1096
+    assert _run(dev, 1, 32, 32, k, 5 * 512, 7, "resblock", seed=k) < 2e-6
+    assert _run(dev, 2, 48, 64, k, T, 7, "accum", seed=k + 1) < 2e-6
+    assert _run(dev, 1, 16, 40, k, T + 4, 7, "act", seed=k + 2) < 2e-6
+    assert _run(dev, 3, 24, 33, k, 516, 7, "slice", seed=k + 3) < 2e-6
+    assert _run(dev, 1, 16, 32, k, 8, 7, "plain", seed=k + 4) < 2e-6            # one tile: no walk
+    assert _run(dev, 1, 40, 64, k, T, 6, "resblock" if False else "plain", seed=k + 5) < 2e-6
+
+
 @pytest.mark.parametrize("d", [3, 5])
 @pytest.mark.parametrize("k", [3, 7, 11])
 def test_g1w_dilated_layers(dev, k, d):
@@ -121,7 +135,7 @@ def test_g1w_fuzz(dev, seed):
     T = 4 * rng.choice([1, 3, 16, 64, 65, 97, 130, 257])
     mode = rng.choice(["plain", "act", "accum", "slice"] + (["resblock"] if co == ci else []))
     d = rng.choice([1, 1, 3, 5]) if k != 5 else 1
-    tile = rng.choice([0, 2, 3]) if d == 1 else 0
+    tile = rng.choice([0, 2, 3, 6, 7]) if d == 1 else 0
     err = _run(dev, n, ci, co, k, T, tile, mode, seed=seed, d=d)
     assert err < 2e-6, ((n, ci, co, k, d, T, mode, tile), err)
 

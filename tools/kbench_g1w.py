@@ -6,7 +6,7 @@ import os, sys, statistics, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from aicovergen_amd import _lib, ops  # noqa: E402
 dev = torch.device("cuda:0")
-NAMES = {-1: "ws3", 0: "policy", 2: "64x256", 3: "32x512", 5: "32x512s"}
+NAMES = {-1: "ws3", 0: "policy", 2: "64x256", 3: "32x512", 5: "32x512s", 6: "pers"}
 codes = [int(c) for c in (sys.argv[1] if len(sys.argv) > 1 else "-1,3,5").split(",")]
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 dils = [int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "1").split(",")]
