@@ -163,11 +163,20 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
             return fail(AICG_E_ARG, "aicg_conv_forward: wino 8 needs stride 1, dilation 1 / 3 / 5, same padding, one group, W %% 4 == 0, 16-byte aligned "
                                     "rows (strides %% 4 == 0), no input activation but a leaky ReLU");
         hipStream_t st8 = (hipStream_t)stream;
-        p.dbg = d->gemm_tile == 7 ? 3 : 0;   // 7: the persistent walk on THREE workgroups (tests: several tiles per workgroup on small maps)
-        // aicg_conv_desc.gemm_tile 2 / 3 force the 64 x 256 / 32 x 512 tile (tools).  Policy: 32 x 512 -- all four waves share the tile's 32
-        // rows, 512 outputs amortise a unit's weights -- won on every layer of the vocoder, 32 to 256 channels (profiles/r05_kbench_g1w*.txt)
-        const int rc = (d->gemm_tile == 2 && p.dw == 1) ? run_g1w_64x256(p, st8) : (d->gemm_tile == 5 && p.dw == 1) ? run_g1w_32x512_sched(p, st8) :
-                       ((d->gemm_tile == 6 || d->gemm_tile == 7) && p.dw == 1) ? run_g1w_32x512_pers(p, st8) : run_g1w_32x512(p, st8);
+        // Tile 32 x 512 -- all four waves share the tile's 32 rows, 512 outputs amortise a unit's weights: it won on every layer of the
+        // vocoder, 32 to 256 channels (profiles/r05_kbench_g1w_*.txt).  Development builds carry the measured-and-lost variants for A/B:
+        // aicg_conv_desc.gemm_tile 2 = the 64 x 256 tile, 5 = explicit MFMA / VALU interleave, 6 = persistent tile walk (2-5 % slower:
+        // profiles/r05_kbench_g1w_persistent.txt), 7 = that walk on three workgroups (tests) -- all for dilation 1
+        int rc;
+        p.dbg = 0;
+#ifdef AICG_DEV_SWITCHES
+        p.dbg = d->gemm_tile == 7 ? 3 : 0;
+        if (p.dw == 1 && d->gemm_tile == 2) rc = run_g1w_64x256(p, st8);
+        else if (p.dw == 1 && d->gemm_tile == 5) rc = run_g1w_32x512_sched(p, st8);
+        else if (p.dw == 1 && (d->gemm_tile == 6 || d->gemm_tile == 7)) rc = run_g1w_32x512_pers(p, st8);
+        else
+#endif
+            rc = run_g1w_32x512(p, st8);
         if (rc == 1) return fail(AICG_E_SHAPE, "aicg_conv_forward: wino 8 layer does not fit the kernel's LDS budget");
         return rc;
     }

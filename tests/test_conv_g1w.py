@@ -48,6 +48,8 @@ def test_slot_kernel_reproduces_the_direct_form():
 
 
 def _run(dev, n, ci, co, k, T, tile, mode, seed=0, expect="conv_g1w_kernel", d=1):
+    if tile in (2, 5, 6, 7) and dev.kind == "hip" and not _lib.get_path().endswith("_dev.so"):
+        pytest.skip("the A/B variants of conv_g1w (64 x 256 tile, explicit interleave, persistent walk) are compiled into development builds only")
     torch.manual_seed(seed)
     x, w, b = torch.randn(n, ci, T), torch.randn(co, ci, k) * 0.2, torch.randn(co)
     pad = (k - 1) // 2 * d
