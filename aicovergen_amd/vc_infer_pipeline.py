@@ -502,10 +502,18 @@ class VC(object):
             many = self._vc_features_many(model, [pad_dev[bounds[ci][0]:bounds[ci][1]] for ci in mine], index, big_npy, index_rate,
                                           version, use_protect)
             feats_of = dict(zip(mine, many))
-            main.synchronize()
-            tf1 = ttime()
-            if progressive and gru_seg.timed_out():    # an early exchange timeout: do not synthesise a whole track from invalid pitch
-                f0_bad = True
+
+            def settle():
+                """The host meets the device: every chunk's features exist.  -> (time, f0 already known to be invalid)"""
+                main.synchronize()
+                # an early exchange timeout: do not synthesise a whole track from invalid pitch
+                return ttime(), bool(progressive and gru_seg.timed_out())
+
+            # Progressive: the host first queues the first chunk's encoder half (below) and settles THEN -- its ~140 short launches
+            # take the host 6 ms to issue, which now pass under the tail of HuBERT instead of in front of the first vocoder.
+            settle_later = progressive
+            if not settle_later:
+                tf1, f0_bad = settle()
             if not progressive:
                 side.synchronize()
                 main.wait_stream(side)
@@ -514,11 +522,13 @@ class VC(object):
                     f0_host = self._rmvpe().infer_from_audio_device(pad_dev, thred=0.03, two_workgroups=False).cpu().numpy()
                 pitch, pitchf = run_f0(f0_host)
                 del f0_dev
-            t2 = ttime()
-            f0_wait = t2 - tf1
-            times[0] += tf1 - tf0
-            times[1] += t2 - tf0  # the f0 branch's own wall time (it overlaps times[0])
+            if not settle_later:
+                t2 = ttime()
+                f0_wait = t2 - tf1
+                times[0] += tf1 - tf0
+                times[1] += t2 - tf0  # the f0 branch's own wall time (it overlaps times[0])
         else:
+            settle_later = False
             if if_f0 == 1:
                 pitch, pitchf = run_f0()
             if self._sync():
@@ -547,8 +557,13 @@ class VC(object):
             pe = None if ci == len(bounds) - 1 else (e - self.window) // self.window
             return pitch[:, s // self.window: pe], pitchf[:, s // self.window: pe]
 
-        # Overlapped schedule: the encoder half of chunk i + 1 (text encoder + flow: a few hundred short launches that leave most
-        # CUs idle) is queued on a second stream underneath the vocoder of chunk i.  AICG_OVERLAP_SYNTH=0: one stream.
+        # Overlapped schedule: the encoder half of chunk i + 1 (text encoder + flow: ~140 short launches that leave most CUs idle
+        # and take the host about as long to queue -- 40 us each -- as the GPU to run) is queued on a second stream underneath the
+        # vocoder of chunk i.  The HOST queues the vocoder of chunk i first and the encoder half of chunk i + 1 behind it: the other way
+        # round the main stream stood idle for the 6 ms the host needs to issue the short launches (kernel trace of round 5,
+        # profiles/r05_timeline.json: 6.5 + 6.1 ms at two chunk boundaries, the first vocoder behind TWO encoder halves).  What that
+        # buys is small -- 2 ms per 240 s track: short launches running beside the vocoder cost it nearly what they take alone
+        # (one stream: 674.7 ms, two: 667) -- and a stream priority changes nothing.  AICG_OVERLAP_SYNTH=0: one stream.
         two_streams = overlap and on_gpu and hasattr(net_g, "infer_front") and os.environ.get("AICG_OVERLAP_SYNTH", "1") != "0"
         fronts = {}
         if two_streams:
@@ -574,6 +589,11 @@ class VC(object):
 
             if order:
                 queue_front(order[0])
+        if settle_later:
+            tf1, f0_bad = settle()
+            t2 = tf1
+            times[0] += tf1 - tf0
+            times[1] += t2 - tf0
 
         def drain():          # the chunk's work is done (progressive: without waiting for the f0 stream's remaining segments)
             if not on_gpu:
@@ -590,11 +610,11 @@ class VC(object):
             pc, pcf = chunk_pitch(ci)
             if two_streams:
                 ts0 = ttime()
-                if k + 1 < len(order):
-                    queue_front(order[k + 1])
                 st, ev, keep = fronts.pop(ci)
                 main.wait_event(ev)
                 out = self._vc_synth_back(net_g, st)[0, 0]
+                if k + 1 < len(order):
+                    queue_front(order[k + 1])
                 drain()
                 del st, keep
                 times[2] += ttime() - ts0
