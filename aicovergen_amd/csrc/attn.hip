@@ -266,39 +266,61 @@ __global__ void __launch_bounds__(256) attn_combine_kernel(AttnArgs p, int D) {
 }
 
 // Relative-position VALUE term: o_i += sum_{|j-i|<=w} P_ij E^v_{j-i+w}, with P rebuilt from the saved
-// log-sum-exp (attentions.py:264-271).  One thread per (query, head); 2w+1 scores in registers.
+// log-sum-exp (attentions.py:264-271).  A workgroup owns 64 queries of one head: the key columns i0 - w .. i0 + 63 + w of all D channels
+// are staged in LDS once (the band of a query is 2w + 1 of them), four waves each contract a quarter of the channels into the
+// 2w + 1 band scores of their query (partial sums met in LDS), the probabilities are formed once per (query, offset), and the four
+// waves each add a quarter of the D output channels.  (The first form -- one thread per query, 64-thread workgroups, every key read
+// from global memory per channel -- took 208 us for T = 6 600, two heads: 2 016 dependent loads per thread on 208 waves.)
 template <int D, int NW>
-__global__ void __launch_bounds__(64) attn_relv_kernel(AttnArgs p, const float* __restrict__ relv_emb) {
+__global__ void __launch_bounds__(256) attn_relv_kernel(AttnArgs p, const float* __restrict__ relv_emb) {
+    constexpr int KC = 64 + NW - 1;             // staged key columns
+    constexpr int DQ = D / 4;                   // channels per wave
     __shared__ float Ev[NW * D];
-    for (int idx = threadIdx.x; idx < NW * D; idx += 64) Ev[idx] = relv_emb[idx];
-    __syncthreads();
-    const int i = blockIdx.x * 64 + threadIdx.x;
+    __shared__ float Ks[D * KC];
+    __shared__ float Ss[4 * NW * 64];           // [channel quarter][offset][query]; quarter 0 becomes the probabilities
+    const int tid = threadIdx.x;
+    const int qi = tid & 63, dg = tid >> 6;
+    const int i0 = blockIdx.x * 64, i = i0 + qi;
     const int h = blockIdx.y;
-    if (i >= p.T) return;
     const int w = p.window;
     const float* qh = p.q + (long)h * D * p.ldq;
     const float* kh = p.k + (long)h * D * p.ldk;
+    for (int idx = tid; idx < NW * D; idx += 256) Ev[idx] = relv_emb[idx];
+    for (int idx = tid; idx < D * KC; idx += 256) {
+        const int d = idx / KC, c = idx - d * KC;
+        const int j = i0 - w + c;
+        Ks[idx] = (j >= 0 && j < p.T) ? kh[(long)d * p.ldk + j] : 0.f;
+    }
+    __syncthreads();
     float s[NW];
 #pragma unroll
     for (int m = 0; m < NW; ++m) s[m] = 0.f;
-    for (int d = 0; d < D; ++d) {
-        const float qd = qh[(long)d * p.ldq + i] * p.scale;
-        const float* kr = kh + (long)d * p.ldk;
+#pragma unroll 2
+    for (int dd = 0; dd < DQ; ++dd) {
+        const int d = dg * DQ + dd;
+        const float qd = i < p.T ? qh[(long)d * p.ldq + i] * p.scale : 0.f;
+        const float* kr = Ks + d * KC + qi;
 #pragma unroll
-        for (int m = 0; m < NW; ++m) {
-            const int j = i + m - w;
-            if (j >= 0 && j < p.T) s[m] += qd * kr[j];
-        }
+        for (int m = 0; m < NW; ++m) s[m] += qd * kr[m];
     }
-    const float lse = p.lse[(long)h * p.T + i];
+#pragma unroll
+    for (int m = 0; m < NW; ++m) Ss[(dg * NW + m) * 64 + qi] = s[m];
+    __syncthreads();
     const float* rk = p.relk + (long)h * NW * p.T;
-#pragma unroll
-    for (int m = 0; m < NW; ++m) {
-        const int j = i + m - w;
-        s[m] = (j >= 0 && j < p.T) ? expf(s[m] + rk[(long)m * p.T + i] - lse) : 0.f;
+    for (int idx = tid; idx < NW * 64; idx += 256) {
+        const int m = idx >> 6, q = idx & 63;
+        const int iq = i0 + q, j = iq + m - w;
+        const float tot = (Ss[idx] + Ss[NW * 64 + idx]) + (Ss[2 * NW * 64 + idx] + Ss[3 * NW * 64 + idx]);
+        Ss[idx] = (iq < p.T && j >= 0 && j < p.T) ? expf(tot + rk[(long)m * p.T + iq] - p.lse[(long)h * p.T + iq]) : 0.f;
     }
+    __syncthreads();
+    if (i >= p.T) return;
+#pragma unroll
+    for (int m = 0; m < NW; ++m) s[m] = Ss[m * 64 + qi];
     float* oh = p.o + (long)h * D * p.ldo;
-    for (int d = 0; d < D; ++d) {
+#pragma unroll 2
+    for (int dd = 0; dd < DQ; ++dd) {
+        const int d = dg * DQ + dd;
         float a = 0.f;
 #pragma unroll
         for (int m = 0; m < NW; ++m) a += s[m] * Ev[m * D + d];
@@ -351,13 +373,13 @@ extern "C" int aicg_attention_relv(const float* q, const float* k, const float* 
     AttnArgs p{q, k, nullptr, relk, o, const_cast<float*>(lse), T, H, window, (long)ldq, (long)ldk, 0, (long)ldo, scale, 1, nullptr};
     dim3 grid((unsigned)idiv_up(T, 64), (unsigned)H);
     if (D == 96 && window == 10)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_relv_kernel<96, 21>), grid, dim3(64), 0, (hipStream_t)stream, p, relv_emb);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_relv_kernel<96, 21>), grid, dim3(256), 0, (hipStream_t)stream, p, relv_emb);
     else if (D == 64 && window == 10)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_relv_kernel<64, 21>), grid, dim3(64), 0, (hipStream_t)stream, p, relv_emb);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_relv_kernel<64, 21>), grid, dim3(256), 0, (hipStream_t)stream, p, relv_emb);
     else if (D == 32 && window == 10)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_relv_kernel<32, 21>), grid, dim3(64), 0, (hipStream_t)stream, p, relv_emb);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_relv_kernel<32, 21>), grid, dim3(256), 0, (hipStream_t)stream, p, relv_emb);
     else if (D == 32 && window == 4)
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_relv_kernel<32, 9>), grid, dim3(64), 0, (hipStream_t)stream, p, relv_emb);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(attn_relv_kernel<32, 9>), grid, dim3(256), 0, (hipStream_t)stream, p, relv_emb);
     else return fail(AICG_E_SHAPE, "aicg_attention_relv: (D=%d, window=%d) not instantiated", D, window);
     return check_launch("attn_relv_kernel");
 }
