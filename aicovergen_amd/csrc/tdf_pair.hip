@@ -96,6 +96,16 @@ __device__ __forceinline__ void tdf_dma_slab(const float* src, float* dst, int n
     for (int c = wave * 64; c < n4; c += 256) lds_dma16(src + 4 * (c + lane), dst + 4 * c, lane);
 }
 
+// piece k of this wave's share of a slab (its pieces are c = wave * 64 + k * 256 < n4): ONE 1 KiB DMA instruction.  The stages issue
+// their next slab a piece at a time between blocks of four MFMAs: a burst of 12-13 pieces per wave at the top of a stage holds the
+// wave -- the only one on its SIMD -- in the issue of the DMA instructions while the CU's LDS-DMA path takes them at ~16 B per clock
+// (ablation, profiles/r05_tdf_pair_ablation.txt: 0.64 + 0.34 ms of the level-0 block's 7.59 were these bursts).
+__device__ __forceinline__ void tdf_dma_piece(const float* src, float* dst, int n4, int tid, int k) {
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = wave * 64 + k * 256;
+    if (c < n4) lds_dma16(src + 4 * (c + lane), dst + 4 * c, lane);
+}
+
 struct XStage { float4 a0, a1, b0, b1; };   // two (row, 8-k group) items of the x slab
 
 __device__ __forceinline__ void tdf_load_x(const TdfArgs& p, int tid, long r0, int st, XStage& v) {
@@ -120,7 +130,10 @@ __device__ __forceinline__ void tdf_commit_x(const TdfArgs& p, float* xbuf, int 
     xdst[((gg + 2) * 2 + 1) * TR + row] = make_float4(v.b0.y, v.b0.w, v.b1.y, v.b1.w);
 }
 
-template <int NH>
+// ABL (development library, AICG_TDF_ABLATE): profiling variants -- 1 no residual loads, 2 no output stores, 4 no phase-2 weight DMA,
+// 8 no phase-1 x loads, 16 no phase-1 weight DMA, 32 no phase-2 MFMAs, 64 no phase-1 MFMAs (results are garbage); 128 the next slab as one
+// burst at the top of the stage (the form up to round 5; results are right)
+template <int NH, int ABL = 0>
 __global__ void __launch_bounds__(256) tdf_pair_kernel(TdfArgs p) {
     constexpr int H = NH * 32;
     constexpr int STAGE = tdf_stage_floats(H);
@@ -145,6 +158,12 @@ __global__ void __launch_bounds__(256) tdf_pair_kernel(TdfArgs p) {
     // committed at the end of the stage; the barrier that opens stage s + 1 follows this wave's vmcnt(0).
     constexpr int W1Q = TK * H / 4;                       // float4 per W1 slab
     constexpr int W2Q = tdf_w2_slab_floats(H) / 4;        // float4 per W2 slab
+    constexpr int NP = (W2Q + 255) / 256;                 // DMA pieces per wave and slab (W1Q <= W2Q)
+    // The next slab goes out a piece at a time between blocks of four MFMAs where a stage has many blocks per piece (H >= 256:
+    // level 0's block 7.58 -> 7.33 ms); the short stages of the deeper levels keep the burst at their top (H = 192: 2.026 against 2.015 ms,
+    // H = 96: 0.508 against 0.496).  ABL bit 128 forces the burst.
+    constexpr bool BURST = NH < 8 || (ABL & 128) != 0;
+    static_assert(NP <= 4 * NH && W1Q <= W2Q, "a stage has a block of four MFMAs per piece");
     XStage xs;
     tdf_dma_slab(p.w1p, smem, W1Q, tid);
     tdf_load_x(p, tid, r0, 0, xs);
@@ -154,11 +173,13 @@ __global__ void __launch_bounds__(256) tdf_pair_kernel(TdfArgs p) {
     for (int st = 0; st < n1; ++st) {
         lds_barrier();   // stage st is in LDS; every wave is done with stage st - 1, whose buffer takes stage st + 1 now
         float* nbuf = smem + ((st + 1) & 1) * STAGE;
-        if (st + 1 < n1) {
-            tdf_dma_slab(p.w1p + (long)(st + 1) * W1Q * 4, nbuf, W1Q, tid);
-            tdf_load_x(p, tid, r0, st + 1, xs);
-        } else {
-            tdf_dma_slab(p.w2p, nbuf, W2Q, tid);
+        // the next stage's weight slab (the last stage: phase 2's first) goes out one piece per block of four MFMAs below
+        const bool more = st + 1 < n1;
+        const float* nsrc = more ? p.w1p + (long)(st + 1) * W1Q * 4 : p.w2p;
+        const int nq = more ? W1Q : W2Q;
+        if constexpr (BURST) tdf_dma_slab(nsrc, nbuf, nq, tid);
+        if (more) {
+            if constexpr ((ABL & 8) == 0) tdf_load_x(p, tid, r0, st + 1, xs);
         }
         const float4* wq = reinterpret_cast<const float4*>(smem + (st & 1) * STAGE) + half * H + l31;
         const float4* xq = reinterpret_cast<const float4*>(smem + (st & 1) * STAGE + TK * H) + half * TR + wave * 32 + l31;
@@ -169,6 +190,10 @@ __global__ void __launch_bounds__(256) tdf_pair_kernel(TdfArgs p) {
 #pragma unroll
             for (int i = 0; i < NH; ++i) {
                 const float4 an = wq[g * 2 * H + (i + 1 < NH ? i + 1 : i) * 32];   // next tile's quad in flight under these MFMAs
+                if constexpr ((ABL & 16) == 0 && !BURST) {
+                    if (g * NH + i < NP) tdf_dma_piece(nsrc, nbuf, nq, tid, g * NH + i);
+                }
+                if constexpr ((ABL & 64) != 0) { acc[i][0] += a.x * b.x + an.y; a = an; continue; }
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[i], 0, 0, 0);
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[i], 0, 0, 0);
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[i], 0, 0, 0);
@@ -210,12 +235,15 @@ __global__ void __launch_bounds__(256) tdf_pair_kernel(TdfArgs p) {
         float4 rx[4], bq4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            rx[q] = row_ok ? *reinterpret_cast<const float4*>(xrow + 32 * fb + 8 * q + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rx[q] = (row_ok && (ABL & 1) == 0) ? *reinterpret_cast<const float4*>(xrow + 32 * fb + 8 * q + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
             bq4[q] = p.b2 ? *reinterpret_cast<const float4*>(p.b2 + 32 * fb + 8 * q + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         // the DMA goes out BEHIND these loads: hipcc guards the re-use of the previous stage's store-data registers with a vmcnt(0),
         // which must only meet stores issued a whole stage ago, not a DMA issued a moment ago (vmcnt retires in order)
-        if (fb + 1 < n2) tdf_dma_slab(p.w2p + (long)(fb + 1) * W2Q * 4, smem + ((st + 1) & 1) * STAGE, W2Q, tid);
+        const float* nsrc = p.w2p + (long)(fb + 1) * W2Q * 4;
+        float* const nbuf = smem + ((st + 1) & 1) * STAGE;
+        const bool more = fb + 1 < n2;
+        if constexpr (BURST) { if (more) tdf_dma_slab(nsrc, nbuf, W2Q, tid); }
         const float4* w2q = reinterpret_cast<const float4*>(smem + (st & 1) * STAGE + l31 * W2LD) + half;   // row f = l31 of the slab
         f32x16 o;
 #pragma unroll
@@ -227,6 +255,10 @@ __global__ void __launch_bounds__(256) tdf_pair_kernel(TdfArgs p) {
             for (int q = 0; q < 4; ++q) {
                 const int nxt = (i * 4 + q + 1 < NH * 4) ? (i * 4 + q + 1) : (i * 4 + q);
                 const float4 an = w2q[(nxt >> 2) * 8 + (nxt & 3) * 2];          // float4 index of h = 32 i' + 8 q' (+ 4 half via the base)
+                if constexpr ((ABL & 4) == 0 && !BURST) {
+                    if (i * 4 + q < NP && more) tdf_dma_piece(nsrc, nbuf, W2Q, tid, i * 4 + q);
+                }
+                if constexpr ((ABL & 32) != 0) { o[0] += a.x * acc[i][4 * q] + an.y; a = an; continue; }
                 o = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, acc[i][4 * q], o, 0, 0, 0);
                 o = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, acc[i][4 * q + 1], o, 0, 0, 0);
                 o = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, acc[i][4 * q + 2], o, 0, 0, 0);
@@ -234,7 +266,7 @@ __global__ void __launch_bounds__(256) tdf_pair_kernel(TdfArgs p) {
                 a = an;
             }
         dma_wait();   // the next slab's DMA (issued a whole stage ago) and this stage's loads; the stores below drain under the next stage
-        if (row_ok) {
+        if (row_ok && ((ABL & 2) == 0 || o[0] == 123.456f)) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int f = 32 * fb + 8 * q + 4 * half;
@@ -251,12 +283,38 @@ __global__ void __launch_bounds__(256) tdf_pair_kernel(TdfArgs p) {
     }
 }
 
+template <int NH, int ABL = 0>
+static int launch_tdf_abl(const TdfArgs& p, hipStream_t st) {
+    const size_t lds = (size_t)2 * tdf_stage_floats(NH * 32) * sizeof(float);
+    allow_dynamic_lds((const void*)tdf_pair_kernel<NH, ABL>, lds);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(tdf_pair_kernel<NH, ABL>), dim3((unsigned)ldiv_up(p.R, TR)), dim3(256), lds, st, p);
+    return check_launch("tdf_pair_kernel");
+}
+
 template <int NH>
 static int launch_tdf(const TdfArgs& p, hipStream_t st) {
-    const size_t lds = (size_t)2 * tdf_stage_floats(NH * 32) * sizeof(float);
-    allow_dynamic_lds((const void*)tdf_pair_kernel<NH>, lds);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(tdf_pair_kernel<NH>), dim3((unsigned)ldiv_up(p.R, TR)), dim3(256), lds, st, p);
-    return check_launch("tdf_pair_kernel");
+#ifdef AICG_DEV_SWITCHES
+    AICG_SWITCH(tdf_ablate, "AICG_TDF_ABLATE", 0);
+    if constexpr (NH == 12) {
+        switch ((int)tdf_ablate) {
+            case 1: return launch_tdf_abl<NH, 1>(p, st);
+            case 2: return launch_tdf_abl<NH, 2>(p, st);
+            case 3: return launch_tdf_abl<NH, 3>(p, st);
+            case 4: return launch_tdf_abl<NH, 4>(p, st);
+            case 7: return launch_tdf_abl<NH, 7>(p, st);
+            case 8: return launch_tdf_abl<NH, 8>(p, st);
+            case 16: return launch_tdf_abl<NH, 16>(p, st);
+            case 24: return launch_tdf_abl<NH, 24>(p, st);
+            case 32: return launch_tdf_abl<NH, 32>(p, st);
+            case 64: return launch_tdf_abl<NH, 64>(p, st);
+            case 96: return launch_tdf_abl<NH, 96>(p, st);
+            case 128: return launch_tdf_abl<NH, 128>(p, st);
+            case 31: return launch_tdf_abl<NH, 31>(p, st);
+            default: break;
+        }
+    }
+#endif
+    return launch_tdf_abl<NH, 0>(p, st);
 }
 
 }  // namespace aicg
