@@ -630,8 +630,8 @@ def attention(q, k, v, n_heads, relk=None, relv_emb=None, window=0, scale=1.0, n
     st = _stream(q)
     # (query block, head) pairs alone do not fill 256 CUs for a few heads: split the keys until ~1024 workgroups exist
     blocks = -(-t // 128) * n_heads
-    # (> 4: the merge pass costs more than it fills; HuBERT's 312 blocks: 3 splits 0.360 ms, 4 0.381, 2 0.398, 6 0.368)
-    splits = max(1, min(4, -(-t // 32), int(1024 / blocks + 0.5))) if n_splits is None else n_splits
+    # (> 4: the merge pass costs more than it fills; HuBERT's 312 blocks, round-5 kernel: 4 splits 0.353 ms, 3 0.361, 2 0.398, 8 0.377)
+    splits = max(1, min(4, -(-t // 32), -(-1024 // blocks))) if n_splits is None else n_splits
     if splits > 1:
         scratch = torch.empty(splits * n_heads * (d + 2) * t, dtype=torch.float32, device=q.device)
         _call("aicg_attention_split", _ptr(q), _ptr(k), _ptr(v), _ptr(relk), _ptr(o), _ptr(lse), t, n_heads, d, window,
