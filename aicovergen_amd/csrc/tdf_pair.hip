@@ -100,10 +100,27 @@ __device__ __forceinline__ void tdf_dma_slab(const float* src, float* dst, int n
 // their next slab a piece at a time between blocks of four MFMAs: a burst of 12-13 pieces per wave at the top of a stage holds the
 // wave -- the only one on its SIMD -- in the issue of the DMA instructions while the CU's LDS-DMA path takes them at ~16 B per clock
 // (ablation, profiles/r05_tdf_pair_ablation.txt: 0.64 + 0.34 ms of the level-0 block's 7.59 were these bursts).
-__device__ __forceinline__ void tdf_dma_piece(const float* src, float* dst, int n4, int tid, int k) {
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+// Eight instructions per piece: the source as an SGPR base (slab + 4 KiB x k, scalar adds) + ONE per-thread byte offset that never
+// changes (16 x thread id: c + lane = tid + 256 k), the LDS destination as scalar arithmetic on the stage buffer's LDS address (no
+// generic-to-LDS pointer cast with its null check per piece), a range check only for the slab's ragged last piece (n4_all = float4
+// count every one of this call's pieces k < n4_all / 256 is inside for all four waves).  The first form cost ~20 issue slots per piece.
+__device__ __forceinline__ void tdf_dma_piece(const float* src, float* dst, unsigned dst_lds, int n4, int tid, unsigned voff16, int wave, int k) {
     const int c = wave * 64 + k * 256;
-    if (c < n4) lds_dma16(src + 4 * (c + lane), dst + 4 * c, lane);
+    if (256 * k + 192 >= n4 && c >= n4) return;            // (the first clause folds at compile time where n4 is a constant)
+#ifdef AICG_EMULATED
+    (void)dst_lds; (void)voff16;
+    const int lane = tid & 63;
+    *reinterpret_cast<float4*>(dst + 4 * c + 4 * lane) = *reinterpret_cast<const float4*>(src + 4 * (c + lane));
+#else
+    (void)dst;
+    const char* sp = reinterpret_cast<const char*>(src) + 4096 * k;
+    const unsigned lds = dst_lds + 1024u * (unsigned)wave + 4096u * (unsigned)k;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff16), "s"(sp), "s"(lds)
+                 : "memory");
+#endif
 }
 
 struct XStage { float4 a0, a1, b0, b1; };   // two (row, 8-k group) items of the x slab
@@ -159,12 +176,18 @@ __global__ void __launch_bounds__(256) tdf_pair_kernel(TdfArgs p) {
     constexpr int W1Q = TK * H / 4;                       // float4 per W1 slab
     constexpr int W2Q = tdf_w2_slab_floats(H) / 4;        // float4 per W2 slab
     constexpr int NP = (W2Q + 255) / 256;                 // DMA pieces per wave and slab (W1Q <= W2Q)
-    // The next slab goes out a piece at a time between blocks of four MFMAs where a stage has many blocks per piece (H >= 256:
-    // level 0's block 7.58 -> 7.33 ms); the short stages of the deeper levels keep the burst at their top (H = 192: 2.026 against 2.015 ms,
-    // H = 96: 0.508 against 0.496).  ABL bit 128 forces the burst.
-    constexpr bool BURST = NH < 8 || (ABL & 128) != 0;
+    // The next slab goes out a piece at a time between blocks of four MFMAs (level 0's block: 7.55 ms as a burst at the top of the stage,
+    // 7.32 with the pieces spread, 6.75 = 137 TFLOP/s with the eight-instruction piece of tdf_dma_piece).  ABL bit 128 forces the burst.
+    constexpr bool BURST = (ABL & 128) != 0;
     static_assert(NP <= 4 * NH && W1Q <= W2Q, "a stage has a block of four MFMAs per piece");
     XStage xs;
+    const int wave_s = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, and said so: what derives from it lives in SGPRs
+    const unsigned voff16 = 16u * (unsigned)tid;          // a thread's byte offset inside a DMA round of the workgroup (pieces of 1 KiB per wave)
+#ifdef AICG_EMULATED
+    const unsigned smem_lds = 0;
+#else
+    const unsigned smem_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem);
+#endif
     tdf_dma_slab(p.w1p, smem, W1Q, tid);
     tdf_load_x(p, tid, r0, 0, xs);
     tdf_commit_x(p, smem + TK * H, tid, r0, xs);
@@ -173,6 +196,7 @@ __global__ void __launch_bounds__(256) tdf_pair_kernel(TdfArgs p) {
     for (int st = 0; st < n1; ++st) {
         lds_barrier();   // stage st is in LDS; every wave is done with stage st - 1, whose buffer takes stage st + 1 now
         float* nbuf = smem + ((st + 1) & 1) * STAGE;
+        const unsigned nbuf_lds = smem_lds + (unsigned)(((st + 1) & 1) * STAGE * 4);
         // the next stage's weight slab (the last stage: phase 2's first) goes out one piece per block of four MFMAs below
         const bool more = st + 1 < n1;
         const float* nsrc = more ? p.w1p + (long)(st + 1) * W1Q * 4 : p.w2p;
@@ -191,7 +215,8 @@ __global__ void __launch_bounds__(256) tdf_pair_kernel(TdfArgs p) {
             for (int i = 0; i < NH; ++i) {
                 const float4 an = wq[g * 2 * H + (i + 1 < NH ? i + 1 : i) * 32];   // next tile's quad in flight under these MFMAs
                 if constexpr ((ABL & 16) == 0 && !BURST) {
-                    if (g * NH + i < NP) tdf_dma_piece(nsrc, nbuf, nq, tid, g * NH + i);
+                    if (g * NH + i < W1Q / 256) tdf_dma_piece(nsrc, nbuf, nbuf_lds, W1Q, tid, voff16, wave_s, g * NH + i);   // (inside both slabs)
+                    else if (g * NH + i < NP && !more) tdf_dma_piece(nsrc, nbuf, nbuf_lds, W2Q, tid, voff16, wave_s, g * NH + i);
                 }
                 if constexpr ((ABL & 64) != 0) { acc[i][0] += a.x * b.x + an.y; a = an; continue; }
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[i], 0, 0, 0);
@@ -242,6 +267,7 @@ __global__ void __launch_bounds__(256) tdf_pair_kernel(TdfArgs p) {
         // which must only meet stores issued a whole stage ago, not a DMA issued a moment ago (vmcnt retires in order)
         const float* nsrc = p.w2p + (long)(fb + 1) * W2Q * 4;
         float* const nbuf = smem + ((st + 1) & 1) * STAGE;
+        const unsigned nbuf_lds = smem_lds + (unsigned)(((st + 1) & 1) * STAGE * 4);
         const bool more = fb + 1 < n2;
         if constexpr (BURST) { if (more) tdf_dma_slab(nsrc, nbuf, W2Q, tid); }
         const float4* w2q = reinterpret_cast<const float4*>(smem + (st & 1) * STAGE + l31 * W2LD) + half;   // row f = l31 of the slab
@@ -256,7 +282,7 @@ __global__ void __launch_bounds__(256) tdf_pair_kernel(TdfArgs p) {
                 const int nxt = (i * 4 + q + 1 < NH * 4) ? (i * 4 + q + 1) : (i * 4 + q);
                 const float4 an = w2q[(nxt >> 2) * 8 + (nxt & 3) * 2];          // float4 index of h = 32 i' + 8 q' (+ 4 half via the base)
                 if constexpr ((ABL & 4) == 0 && !BURST) {
-                    if (i * 4 + q < NP && more) tdf_dma_piece(nsrc, nbuf, W2Q, tid, i * 4 + q);
+                    if (i * 4 + q < NP && more) tdf_dma_piece(nsrc, nbuf, nbuf_lds, W2Q, tid, voff16, wave_s, i * 4 + q);
                 }
                 if constexpr ((ABL & 32) != 0) { o[0] += a.x * acc[i][4 * q] + an.y; a = an; continue; }
                 o = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, acc[i][4 * q], o, 0, 0, 0);
