@@ -199,7 +199,16 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
                 if (ra != 1) return ra;
                 return fail(AICG_E_ARG, "aicg_conv_forward: AICG_CONV_ABLATE=%ld is not an instantiated variant of conv_w2d (or not the dev library)", (long)w2d_ablate);
             }
-            const int rc = d->wino == 2 ? run_w2d_8(p, st2) : d->wino == 3 ? run_w2d_4(p, st2) : d->wino == 4 ? run_w2d_8q(p, st2) : run_w2d_4q(p, st2);
+#ifdef AICG_DEV_SWITCHES
+            // dev library, for round-robin A/B in one process (tools/kbench_w2d_ab.py): 6 = the eight-wave form with the round-5 stage burst
+            if (d->wino == 6) return run_w2d_ablation(p, st2, 512);
+            if (d->wino == 7) return run_w2d_ablation(p, st2, 1024);   // patch pieces from one L2-resident KiB (wrong results)
+            if (d->wino == 9) return run_w2d_ablation(p, st2, 2048);   // no patch pieces at all (wrong results)
+            if (d->wino == 10) return run_w2d_ablation(p, st2, 1);     // no DMA at all (wrong results)
+#endif
+            // 12: eight waves on the PAIR-fragment image ([s][p / 2][ks][m][p % 2]: one 8-byte fragment read per two MFMAs)
+            const int rc = d->wino == 2 ? run_w2d_8(p, st2) : d->wino == 3 ? run_w2d_4(p, st2) : d->wino == 4 ? run_w2d_8q(p, st2)
+                         : d->wino == 12 ? run_w2d_8p(p, st2) : run_w2d_4q(p, st2);
             if (rc == 1)
                 return fail(AICG_E_ARG, "aicg_conv_forward: wino 2 needs Cout %% 48 == 0, W %% 4 == 0, 16-byte aligned x with strides %% 4 == 0");
             return rc;

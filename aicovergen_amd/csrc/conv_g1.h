@@ -95,6 +95,15 @@ __device__ __forceinline__ void g1_epilogue(const ConvArgs& p, f32x16 (&acc)[TM]
                 }
         } else {
             const long y_col = (long)img * p.y_sn + pos, r_col = (long)img * p.r_sn + pos;
+            // ONE statement of the per-element epilogue (additive residual before / after the activation, output scale, accumulate), used
+            // by the float4 path and by the ragged last quad alike.  (res_mul is the SHUF branch's; conv_g1s_applicable() rejects it,
+            // so RAGGED never meets it.)
+            auto elem = [&](float x, float rr, float yy) __attribute__((always_inline)) {
+                if (p.res_first) x += rr;
+                x = act_static<ACT>(x, p.act, p.act_slope);
+                if (!p.res_first) x += rr;
+                return x * p.out_scale + yy;
+            };
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -109,13 +118,9 @@ __device__ __forceinline__ void g1_epilogue(const ConvArgs& p, f32x16 (&acc)[TM]
 #pragma unroll
                             for (int t = 0; t < 3; ++t) {
                                 if (t >= nvalid) break;
-                                float x = v[t];
                                 const float rr1 = p.res ? p.res[r_col + (long)m * p.r_sc + t] : 0.f;
-                                if (p.res_first) x += rr1;
-                                x = act_static<ACT>(x, p.act, p.act_slope);
-                                if (!p.res_first) x += rr1;
                                 float* dst1 = p.y + y_col + (long)m * p.y_sc + t;
-                                *dst1 = x * p.out_scale + (p.accumulate ? *dst1 : 0.f);
+                                *dst1 = elem(v[t], rr1, p.accumulate ? *dst1 : 0.f);
                             }
                             continue;
                         }
@@ -124,13 +129,7 @@ __device__ __forceinline__ void g1_epilogue(const ConvArgs& p, f32x16 (&acc)[TM]
                     if (p.accumulate) yv = *reinterpret_cast<const float4*>(p.y + y_col + (long)m * p.y_sc);
                     const float rr[4] = {rv.x, rv.y, rv.z, rv.w}, yy[4] = {yv.x, yv.y, yv.z, yv.w};
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        float x = v[t];
-                        if (p.res_first) x += rr[t];
-                        x = act_static<ACT>(x, p.act, p.act_slope);
-                        if (!p.res_first) x += rr[t];
-                        v[t] = x * p.out_scale + yy[t];
-                    }
+                    for (int t = 0; t < 4; ++t) v[t] = elem(v[t], rr[t], yy[t]);
                     *reinterpret_cast<float4*>(p.y + y_col + (long)m * p.y_sc) = make_float4(v[0], v[1], v[2], v[3]);
                 }
         }

@@ -477,6 +477,8 @@ inline bool conv_g1w_applicable(const ConvArgs& p, int pad_w_end) {
     if (p.shuffle || p.res_mul || p.W >= (1 << 24) || p.x_sc >= (1L << 24) || p.x_sc < p.W) return false;
     if (!al(p.x) || !m4(p.x_sn) || !m4(p.x_sc) || !al(p.y) || !m4(p.y_sn) || !m4(p.y_sc)) return false;
     if (p.res && (!al(p.res) || !m4(p.r_sn) || !m4(p.r_sc))) return false;
+    const long nslot = p.KW == 3 ? 4 : p.KW == 5 ? 7 : p.KW == 7 ? 10 : 15;
+    if (nslot * p.Cin_pad * p.Mpad * 4 >= (1L << 31)) return false;                        // 32-bit byte offsets inside the slot image
     return true;
 }
 

@@ -71,6 +71,73 @@ __device__ __forceinline__ void w2d_dma16(const BufRsrc& r, unsigned voff, unsig
                  : "memory");
 #endif
 }
+// A RUN of N <= 4 pieces of one resource whose LDS destinations are consecutive KiB (piece e lands at lds_base + 1 KiB x e), issued as ONE
+// statement with one M0 save / restore (N calls of w2d_dma16 are 9 N instructions + a generic-to-LDS pointer cast with its null check
+// each; profiles/NOTES.md R6: the probe's L2-resident burst of 48 pieces lands at 44 B per clock and CU, while conv_w2d's waves stood
+// ~3 000 cycles per stage in ~150 issue slots of address arithmetic and three exposed LDS reads).
+//   SAME: a contiguous slab (the weights) -- every piece uses the per-lane offset v[0] and the wave-uniform `soff`; the instruction's
+//         12-bit immediate advances the memory AND the LDS address by 1 KiB x e (LDS_ADDR = M0 base + inst_offset + 16 x lane): N + 4
+//         instructions;
+//   else: piece e has its own per-lane offsets v[e] (the patch; kBufOob = padding) and M0 itself is advanced: 3 N + 2 instructions.
+template <int N, bool SAME>
+__device__ __forceinline__ void w2d_dma_run(const BufRsrc& r, const unsigned (&v)[4], unsigned soff, float* lds_base, unsigned lds_addr, int lane) {
+    static_assert(N >= 1 && N <= 4, "the immediate offset has 12 bits");
+#ifdef AICG_EMULATED
+    (void)lds_addr;
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        const unsigned voff = SAME ? v[0] + 1024u * e : v[e];      // the hardware range-checks voff + the immediate (not the scalar offset)
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned long)voff + 16 <= r.num_records) __builtin_memcpy(&q, r.base + voff + soff, 16);
+        *reinterpret_cast<float4*>(lds_base + 256 * e + 4 * lane) = q;
+    }
+#else
+    (void)lane; (void)lds_base;
+    buf_i32x4 rs;
+    rs.x = __builtin_amdgcn_readfirstlane(r.d.x); rs.y = __builtin_amdgcn_readfirstlane(r.d.y);
+    rs.z = __builtin_amdgcn_readfirstlane(r.d.z); rs.w = __builtin_amdgcn_readfirstlane(r.d.w);
+    const unsigned lds = __builtin_amdgcn_readfirstlane(lds_addr);
+    const unsigned so = __builtin_amdgcn_readfirstlane(soff);
+    unsigned keep;
+#define W2D_HEAD "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+#define W2D_TAIL "s_mov_b32 m0, %0"
+#define W2D_BUMP "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+    if constexpr (SAME) {
+        if constexpr (N == 1)
+            asm volatile(W2D_HEAD "buffer_load_dwordx4 %4, %1, %3 offen lds\n\t" W2D_TAIL
+                         : "=&s"(keep) : "s"(rs), "s"(lds), "s"(so), "v"(v[0]) : "memory");
+        else if constexpr (N == 2)
+            asm volatile(W2D_HEAD "buffer_load_dwordx4 %4, %1, %3 offen lds\n\tbuffer_load_dwordx4 %4, %1, %3 offen offset:1024 lds\n\t" W2D_TAIL
+                         : "=&s"(keep) : "s"(rs), "s"(lds), "s"(so), "v"(v[0]) : "memory");
+        else if constexpr (N == 3)
+            asm volatile(W2D_HEAD "buffer_load_dwordx4 %4, %1, %3 offen lds\n\tbuffer_load_dwordx4 %4, %1, %3 offen offset:1024 lds\n\t"
+                         "buffer_load_dwordx4 %4, %1, %3 offen offset:2048 lds\n\t" W2D_TAIL
+                         : "=&s"(keep) : "s"(rs), "s"(lds), "s"(so), "v"(v[0]) : "memory");
+        else
+            asm volatile(W2D_HEAD "buffer_load_dwordx4 %4, %1, %3 offen lds\n\tbuffer_load_dwordx4 %4, %1, %3 offen offset:1024 lds\n\t"
+                         "buffer_load_dwordx4 %4, %1, %3 offen offset:2048 lds\n\tbuffer_load_dwordx4 %4, %1, %3 offen offset:3072 lds\n\t" W2D_TAIL
+                         : "=&s"(keep) : "s"(rs), "s"(lds), "s"(so), "v"(v[0]) : "memory");
+    } else {
+        if constexpr (N == 1)
+            asm volatile(W2D_HEAD "buffer_load_dwordx4 %4, %1, %3 offen lds\n\t" W2D_TAIL
+                         : "=&s"(keep) : "s"(rs), "s"(lds), "s"(so), "v"(v[0]) : "memory");
+        else if constexpr (N == 2)
+            asm volatile(W2D_HEAD "buffer_load_dwordx4 %4, %1, %3 offen lds\n\t" W2D_BUMP "buffer_load_dwordx4 %5, %1, %3 offen lds\n\t" W2D_TAIL
+                         : "=&s"(keep) : "s"(rs), "s"(lds), "s"(so), "v"(v[0]), "v"(v[1]) : "memory", "scc");
+        else if constexpr (N == 3)
+            asm volatile(W2D_HEAD "buffer_load_dwordx4 %4, %1, %3 offen lds\n\t" W2D_BUMP "buffer_load_dwordx4 %5, %1, %3 offen lds\n\t"
+                         W2D_BUMP "buffer_load_dwordx4 %6, %1, %3 offen lds\n\t" W2D_TAIL
+                         : "=&s"(keep) : "s"(rs), "s"(lds), "s"(so), "v"(v[0]), "v"(v[1]), "v"(v[2]) : "memory", "scc");
+        else
+            asm volatile(W2D_HEAD "buffer_load_dwordx4 %4, %1, %3 offen lds\n\t" W2D_BUMP "buffer_load_dwordx4 %5, %1, %3 offen lds\n\t"
+                         W2D_BUMP "buffer_load_dwordx4 %6, %1, %3 offen lds\n\t" W2D_BUMP "buffer_load_dwordx4 %7, %1, %3 offen lds\n\t" W2D_TAIL
+                         : "=&s"(keep) : "s"(rs), "s"(lds), "s"(so), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]) : "memory", "scc");
+    }
+#undef W2D_HEAD
+#undef W2D_TAIL
+#undef W2D_BUMP
+#endif
+}
 __device__ __forceinline__ void w2d_dma_wait() {
 #ifndef AICG_EMULATED
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -89,17 +156,26 @@ __device__ inline T w2d_opaque(T v) {   // a per-item copy of a uniform value th
     return v;
 }
 
-// PF: points a fragment is fetched ahead (dword fragments: weights [s][p][ks][m]); PF == 0: QUAD fragments -- weights
-// [s][p / 4][ks][m][p % 4], one ds_read_b128 per (point group, row block) feeding four MFMAs, reloaded in place behind them.
+// PF 1 / 3: points a fragment is fetched ahead (dword fragments: weights [s][p][ks][m]); PF == 0: QUAD fragments -- weights
+// [s][p / 4][ks][m][p % 4], one ds_read_b128 per (point group, row block) feeding four MFMAs, reloaded in place behind them; PF == 2: PAIR
+// fragments -- [s][p / 2][ks][m][p % 2], one ds_read_b64 per two MFMAs.
 // ABL: profiling variants, instantiated in the dev library only (tools/kbench_w2d_ablate.py): 1 no DMA, 2 no fragment reads, 4 no patch
 // reads / transform, 8 no MFMAs, 16 no epilogue, 32 no stage barriers, 64 clocks of workgroup 0 into y[0..1], 128 epilogue without its
-// stores.  Compile-time: a run-time switch in the k-step loop costs the 8-wave form its register budget.
+// stores, 512 the round-4 / 5 stage burst (one w2d_dma16 per piece, pieces w, w + NW, ... of the patch) for A/B against the runs of
+// w2d_dma_run.  Compile-time: a run-time switch in the k-step loop costs the 8-wave form its register budget.
 template <int NW, int PF, int ABL = 0>
 __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
     constexpr int dbg = ABL;
+    constexpr bool OLD_DMA = (ABL & 512) != 0;
     constexpr int BUFS = 3;                          // stage g computes, stage g + 1 has landed (k-step (g, 1) reads ahead into it), stage g + 2 is being filled
-    static_assert(PF == 0 || PF == 1 || PF == 3, "the fragment ring has PF + 1 slots and 16 points are a whole number of turns");
-    constexpr bool AQ = PF == 0;
+    static_assert(PF == 0 || PF == 1 || PF == 2 || PF == 3, "PF 1 / 3: a fragment ring of PF + 1 slots (16 points are a whole number of turns); 0 / 2: groups");
+    // PF == 0 / 2: GROUP fragments -- the weights of G = 4 / 2 consecutive points side by side in LDS ([s][p / G][ks][m][p % G]): one
+    // ds_read_b128 / ds_read_b64 per (point group, row block) feeds G MFMAs and is reloaded in place right behind them.  Every LDS read
+    // whose result the matrix pipe consumes costs the pipe a bubble whatever its width (profiles/NOTES.md 2.2: 256 against 192 cycles per
+    // k-step with dword fragments, 204 with one b128 per four): pairs halve the 96 reads of a stage in the SAME six registers the
+    // dword ring holds (quads need twelve: 77 spills in the eight-wave form).
+    constexpr bool AQ = PF == 0 || PF == 2;
+    constexpr int G = PF == 0 ? 4 : 2;                // points per fragment group (AQ)
     constexpr int NT = 64 * NW;
     constexpr int PROWS = NW + 2;                                 // patch rows
     constexpr int PLANEQ = w2d_plane_quads(NW);
@@ -109,6 +185,11 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
     HIP_DYNAMIC_SHARED(float4, smem4)
     float* const smem = reinterpret_cast<float*>(smem4);
     float* const bias_s = smem + BUFS * STAGE;       // Cout: the layer's bias
+#ifdef AICG_EMULATED
+    const unsigned smem_lds = 0;
+#else
+    const unsigned smem_lds = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem);
+#endif
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, and said so: everything derived from it lives in SGPRs
     // Per-lane constants are RE-DERIVED from the thread id wherever they are used instead of being kept: besides its 192 accumulators a
@@ -142,7 +223,7 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
     unsigned* const tab_s = reinterpret_cast<unsigned*>(bias_s + ((nmu * kW2dM + 3) & ~3));   // [2][NPP][NT]: decode, then offsets
 #pragma unroll
     for (int e = 0; e < NPP; ++e) {
-        const int piece = wave + NW * e;
+        const int piece = OLD_DMA ? wave + NW * e : wave * NPP + e;   // a wave's pieces are consecutive KiB of the stage: one run (w2d_dma_run)
         const int Q = piece * 64 + (tid & 63);
         const int c = Q / PLANEQ, rem = Q - c * PLANEQ;
         const int row = rem / kW2dPQuads, qd = rem - row * kW2dPQuads;
@@ -163,7 +244,9 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
             const int c = (int)(dcd >> 16), row = (int)((dcd >> 8) & 255u), qd = (int)(dcd & 255u);
             const int hin = h0 - 1 + row, win = w0 - 4 + 4 * qd;
             const bool ok = dcd != 0xffffffffu && hin >= 0 && hin < p.H && win >= 0 && win + 4 <= p.W;
-            tl[(NPP + e) * NT] = ok ? 4u * (unsigned)(c * (int)p.x_sc + hin * (int)p.x_sh + win) : kBufOob;
+            // ABL 1024: every patch piece reads the same L2-resident KiB (wrong results): what the HBM side of the burst costs
+            if constexpr ((dbg & 1024) != 0) tl[(NPP + e) * NT] = 16u * (unsigned)lane_now();
+            else tl[(NPP + e) * NT] = ok ? 4u * (unsigned)(c * (int)p.x_sc + hin * (int)p.x_sh + win) : kBufOob;
         }
     };
     auto issue = [&](float* buf) __attribute__((always_inline)) {   // the next stage of the walk = (item li, chunk lc) into `buf`: one burst
@@ -173,18 +256,45 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
         const int lane = lane_now();
         const long wbase = ((long)lmu * nchunk + lc) * kW2dWFloats;
         const BufRsrc wb = make_buf(p.w3 + wbase, (unsigned)(kW2dWFloats * 4));
-#pragma unroll
-        for (int e = 0; e < WPW; ++e) {
-            const int piece = wave * WPW + e;
-            w2d_dma16(wb, 16u * (unsigned)lane, 1024u * (unsigned)piece, buf + piece * 256, lane);
-        }
         const long left = (long)(p.Cin_g - lc * 8) * p.x_sc * 4;   // bytes up to the end of the image's channels: absent channels read 0
         const BufRsrc xb = make_buf(xg + (long)lc * 8 * p.x_sc, (unsigned)lmin(left, 0x7fffffffL));
-        const unsigned* tl = tab_s + NPP * NT + wave * 64 + lane;
+        if constexpr (OLD_DMA) {
 #pragma unroll
-        for (int e = 0; e < NPP; ++e) {
-            const int piece = wave + NW * e;
-            if (piece < PPIECES) w2d_dma16(xb, tl[e * NT], 0u, buf + kW2dWFloats + piece * 256, lane);
+            for (int e = 0; e < WPW; ++e) {
+                const int piece = wave * WPW + e;
+                w2d_dma16(wb, 16u * (unsigned)lane, 1024u * (unsigned)piece, buf + piece * 256, lane);
+            }
+            const unsigned* tl = tab_s + NPP * NT + wave * 64 + lane;
+#pragma unroll
+            for (int e = 0; e < NPP; ++e) {
+                const int piece = wave + NW * e;
+                if (piece < PPIECES) w2d_dma16(xb, tl[e * NT], 0u, buf + kW2dWFloats + piece * 256, lane);
+            }
+        } else {
+            // the stage buffer's LDS byte address as scalar arithmetic on the workgroup's LDS base (no generic-to-LDS cast per piece)
+            const unsigned buf_lds = smem_lds + (unsigned)(buf - smem) * 4u;
+            // the patch offsets of this wave's pieces: read FIRST, they land under the weight pieces
+            const unsigned* tl = tab_s + NPP * NT + wave * 64 + lane;
+            unsigned po[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int e = 0; e < NPP; ++e) po[e] = tl[e * NT];
+            const unsigned wv[4] = {16u * (unsigned)lane, 0u, 0u, 0u};
+            static_assert(WPW == 3 || WPW == 6, "weight pieces per wave");
+            w2d_dma_run<3, true>(wb, wv, 1024u * (unsigned)(wave * WPW), buf + wave * WPW * 256, buf_lds + 1024u * (unsigned)(wave * WPW), lane);
+            if constexpr (WPW == 6)
+                w2d_dma_run<3, true>(wb, wv, 1024u * (unsigned)(wave * WPW + 3), buf + (wave * WPW + 3) * 256,
+                                     buf_lds + 1024u * (unsigned)(wave * WPW + 3), lane);
+            // this wave's patch pieces wave NPP .. + NPP - 1 (the last wave may own fewer: PPIECES is not a multiple of NW)
+            float* pdst = buf + kW2dWFloats + wave * NPP * 256;
+            const unsigned pdst_lds = buf_lds + (unsigned)(kW2dWFloats * 4) + 1024u * (unsigned)(wave * NPP);
+            const int mine_p = PPIECES - wave * NPP;          // >= NPP except on the last wave
+            if constexpr ((dbg & 2048) != 0) { (void)pdst; (void)pdst_lds; (void)mine_p; }   // ABL 2048: weights only (wrong results)
+            else if (mine_p >= NPP) w2d_dma_run<NPP, false>(xb, po, 0u, pdst, pdst_lds, lane);
+            else {
+                constexpr int LASTN = PPIECES - (NW - 1) * NPP;   // 23 - 21 = 2 (eight waves), 15 - 12 = 3 (four)
+                static_assert(LASTN >= 1 && LASTN <= NPP, "the last wave owns at least one piece");
+                w2d_dma_run<LASTN, false>(xb, po, 0u, pdst, pdst_lds, lane);
+            }
         }
         if (++lc == nchunk) { lc = 0; ++li; }
     };
@@ -195,7 +305,8 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
     float2 raw[4][3];                                // the next k-step's patch as loaded: [patch row][aligned column pair]
     float N[4][4];                                   // ... on its way to V: R = B^T d, then V = R B in place
     float ring[PF + 1][3];                           // A fragments: slot pt & PF holds point pt's, fetched PF points ahead
-    float4 aq[3];                                    // AQ: the running point group's fragments per row block (x .. w = points 4 pg .. + 3)
+    float4 aq[3];                                    // AQ, G == 4: the running point group's fragments per row block (x .. w = points 4 pg .. + 3)
+    float2 ap[3];                                    // AQ, G == 2: ... (x, y = points 2 pg, 2 pg + 1)
     // lane-relative LDS offsets: patch (in float2 units: 8-byte reads) = plane of channel ks, patch row 2 (w >> 1), column pair
     // 16 (w & 1) + l15 -- the aligned pair that starts at input column 2 j - 2; weights (floats) = row l15 of lane group ks
     int p_lane2 = 0, w_lane = 0, l15 = 0, ks = 0;
@@ -246,7 +357,8 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
     };
     auto fetch_q = [&](const float* stage, int s, int pg, int rb) __attribute__((always_inline)) {      // AQ: row block rb's fragments of point group pg of k-step s
         if constexpr ((dbg & 2) != 0) return;
-        aq[rb] = reinterpret_cast<const float4*>(__builtin_assume_aligned(stage, 16))[(s * 4 + pg) * 4 * kW2dM + ks * kW2dM + rb * 16 + l15];
+        if constexpr (G == 4) aq[rb] = reinterpret_cast<const float4*>(__builtin_assume_aligned(stage, 16))[(s * 4 + pg) * 4 * kW2dM + ks * kW2dM + rb * 16 + l15];
+        else ap[rb] = reinterpret_cast<const float2*>(__builtin_assume_aligned(stage, 16))[(s * 8 + pg) * 4 * kW2dM + ks * kW2dM + rb * 16 + l15];
     };
     auto fetch_a = [&](const float* stage, int s, int pt, int slot_) __attribute__((always_inline)) {   // fragments of point pt of k-step s of the stage at `stage`
         if constexpr ((dbg & 2) != 0) return;
@@ -264,22 +376,27 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
         constexpr bool FIRST = decltype(first_tag)::value;
         constexpr bool PREP = decltype(prep_tag)::value;     // read and transform the next k-step's patch, fetch its first fragments
         if constexpr (AQ) {
-            // twelve steps (point group pg, row block rb) of four MFMAs; the step's fragment quad is reloaded in place right behind
-            // them with the same row block's quad of the next group (next k-step after the last): 8 MFMAs = 256 cycles to land
+            // 3 x 16 / G steps (point group pg, row block rb) of G MFMAs; the step's fragment group is reloaded in place right behind
+            // them with the same row block's group of the next point group (next k-step after the last): two steps = 2 G MFMAs of this
+            // wave (and as many of the SIMD's other wave) to land.  The preparation of the next k-step sits where it sat in the quad
+            // form: patch rows read behind steps at 1/2 and 7/12 of the k-step, transformed under the last third.
+            constexpr int NG = 16 / G, NST = 3 * NG, SC = NST / 12;
 #pragma unroll
-            for (int st = 0; st < 12; ++st) {
+            for (int st = 0; st < NST; ++st) {
                 const int pg = st / 3, rb = st - 3 * pg;
                 w2d_fence();
                 if constexpr ((dbg & 4) == 0 && PREP) {
-                    if (st == 8) rows_to_R(0, 2);
-                    else if (st == 9) rows_to_R(2, 4);
-                    else if (st == 10) R_to_V(0, 2);
-                    else if (st == 11) R_to_V(2, 4);
+                    if (st == 8 * SC) rows_to_R(0, 2);
+                    else if (st == 9 * SC) rows_to_R(2, 4);
+                    else if (st == 10 * SC) R_to_V(0, 2);
+                    else if (st == 11 * SC) R_to_V(2, 4);
                 }
 #pragma unroll
-                for (int p4 = 0; p4 < 4; ++p4) {
-                    const int pt = 4 * pg + p4;
-                    const float av = p4 == 0 ? aq[rb].x : p4 == 1 ? aq[rb].y : p4 == 2 ? aq[rb].z : aq[rb].w;
+                for (int p4 = 0; p4 < G; ++p4) {
+                    const int pt = G * pg + p4;
+                    float av;
+                    if constexpr (G == 4) av = p4 == 0 ? aq[rb].x : p4 == 1 ? aq[rb].y : p4 == 2 ? aq[rb].z : aq[rb].w;
+                    else av = p4 == 0 ? ap[rb].x : ap[rb].y;
                     if constexpr ((dbg & 8) != 0) { if constexpr (FIRST) acc[pt][rb] = w2d_f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
                     if constexpr (FIRST) {
                         acc[pt][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, V[pt], w2d_f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -288,10 +405,11 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
                     }
                 }
                 w2d_fence();
-                if (pg < 3) fetch_q(cur, s, pg + 1, rb);
+                if (pg < NG - 1) fetch_q(cur, s, pg + 1, rb);
                 else if constexpr (PREP) fetch_q(nxt, sn, 0, rb);
                 if constexpr ((dbg & 4) == 0 && PREP) {
-                    if (st == 6 || st == 7) load_raw(nxt, sn, 2 * (st - 6), 2 * (st - 6) + 2);
+                    if (st == 6 * SC) load_raw(nxt, sn, 0, 2);
+                    else if (st == 7 * SC) load_raw(nxt, sn, 2, 4);
                 }
             }
             if constexpr (PREP) take_V();
@@ -503,6 +621,7 @@ static int launch_conv_w2d(ConvArgs& p, hipStream_t stream) {
 int run_w2d_8(ConvArgs& p, hipStream_t st);
 int run_w2d_4(ConvArgs& p, hipStream_t st);
 int run_w2d_8q(ConvArgs& p, hipStream_t st);
+int run_w2d_8p(ConvArgs& p, hipStream_t st);   // eight waves on PAIR fragments (image [s][p / 2][ks][m][p % 2])
 int run_w2d_4q(ConvArgs& p, hipStream_t st);
 int run_w2d_ablation(ConvArgs& p, hipStream_t st, int bits);   // dev library only: the 8-wave form with ABL = bits (1 = unknown variant)
 

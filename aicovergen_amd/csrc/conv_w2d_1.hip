@@ -4,5 +4,6 @@ namespace aicg {
 int run_w2d_8(ConvArgs& p, hipStream_t st) { return launch_conv_w2d<8, 1>(p, st); }
 int run_w2d_4(ConvArgs& p, hipStream_t st) { return launch_conv_w2d<4, 3>(p, st); }
 int run_w2d_8q(ConvArgs& p, hipStream_t st) { return launch_conv_w2d<8, 0>(p, st); }
+int run_w2d_8p(ConvArgs& p, hipStream_t st) { return launch_conv_w2d<8, 2>(p, st); }
 int run_w2d_4q(ConvArgs& p, hipStream_t st) { return launch_conv_w2d<4, 0>(p, st); }
 }  // namespace aicg

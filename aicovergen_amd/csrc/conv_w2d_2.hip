@@ -19,6 +19,9 @@ int run_w2d_ablation(ConvArgs& p, hipStream_t st, int bits) {
         case 1 | 16: return launch_conv_w2d<8, 1, 1 | 16>(p, st);
         case 2 | 4: return launch_conv_w2d<8, 1, 2 | 4>(p, st);
         case 256: return launch_conv_w2d<8, 1, 256>(p, st);
+        case 512: return launch_conv_w2d<8, 1, 512>(p, st);
+        case 1024: return launch_conv_w2d<8, 1, 1024>(p, st);
+        case 2048: return launch_conv_w2d<8, 1, 2048>(p, st);
         default: return 1;
     }
 }

@@ -45,12 +45,18 @@ def single(ws, group=None):
     return not (force_collectives and not isinstance(group, str) and td.is_available() and td.is_initialized())
 
 
+# bench.py's instrumented step sets this: time every keyed collective with the device drained on both sides.  Off (the default, and in
+# bench.py's TIMED steps): collectives are only counted -- a production step carries no device-wide drain for bookkeeping.
+profile_joins = False
+
+
 def _timed(key, fn, device_tensor):
-    """Run a data-path collective; its wall time (device drained on both sides) is added to last_join[key] for bench.py's per-rank
-    split.  Only the multi-rank / forced paths come here.  key None: counted, not timed -- the f0 branch's joins are queued on a
-    side stream under the HuBERT pass, and draining the device there would serialise the two branches."""
+    """Run a data-path collective.  With `profile_joins` its wall time (device drained on both sides) is added to last_join[key] for
+    bench.py's per-rank split; otherwise it is only counted.  Only the multi-rank / forced paths come here.  key None: never timed --
+    the f0 branch's joins are queued on a side stream under the HuBERT pass, and draining the device there would serialise the two
+    branches."""
     last_join["collectives"] = last_join.get("collectives", 0) + 1
-    if key is None:
+    if key is None or not profile_joins:
         return fn()
     cuda = device_tensor.is_cuda
     if cuda:

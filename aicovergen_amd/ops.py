@@ -236,9 +236,19 @@ winograd2d_waves = int(os.environ.get("AICG_W2D_WAVES", "8"))   # 8: two waves p
 
 winograd2d_code = int(os.environ.get("AICG_W2D_CODE", "0"))       # tools: a schedule variant under test (aicg_conv_desc.wino 6 ..)
 winograd2d_quads = os.environ.get("AICG_W2D_QUADS", "0") == "1"   # fragment image: [s][p / 4][ks][m][p % 4] (16-byte fragments)
+# the eight-wave form reads PAIR fragments ([s][p / 2][ks][m][p % 2], one ds_read_b64 per two MFMAs: aicg_conv_desc.wino 12) unless
+# AICG_W2D_PAIRS=0 (dword fragments, wino 2): 1-6 % faster on the five MDX-Net levels (profiles/r06_kbench_w2d_pairs.txt)
+winograd2d_pairs = os.environ.get("AICG_W2D_PAIRS", "1") != "0"
 
 
-def winograd2d_image(w, quads=False):
+def _w2d_code():
+    """aicg_conv_desc.wino of a layer on the two-dimensional form, and which image it reads ("dword" / "pairs" / "quads")."""
+    code = winograd2d_code or ((4 if winograd2d_quads else 12 if winograd2d_pairs else 2) if winograd2d_waves == 8
+                               else (5 if winograd2d_quads else 3))
+    return code, ("pairs" if code == 12 else "quads" if code in (4, 5) else "dword")
+
+
+def winograd2d_image(w, quads=False, pairs=False):
     """(Cout, Cin, 3, 3), Cout % 48 == 0 -> the image aicg_conv_desc.wino == 2 reads (include/aicg.h): U = G g G^T per (co, ci), laid out
     [Cout / 48][ceil(Cin / 8)][s][point 4 i + q][ks][m] with input channel 8 chunk + 4 s + ks (zero beyond Cin); `quads`:
     [Cout / 48][ceil(Cin / 8)][s][point / 4][ks][m][point % 4] (wino == 4 / 5)."""
@@ -251,6 +261,8 @@ def winograd2d_image(w, quads=False):
     Up[:, :ci] = U.reshape(co, ci, 16)
     if quads:
         return Up.view(co // 48, 48, cpad // 8, 2, 4, 4, 4).permute(0, 2, 3, 5, 4, 1, 6).contiguous().view(-1)
+    if pairs:   # [Cout / 48][ceil(Cin / 8)][s][point / 2][ks][m][point % 2] (wino == 12)
+        return Up.view(co // 48, 48, cpad // 8, 2, 4, 8, 2).permute(0, 2, 3, 5, 4, 1, 6).contiguous().view(-1)
     return Up.view(co // 48, 48, cpad // 8, 2, 4, 16).permute(0, 2, 3, 5, 4, 1).contiguous().view(-1)
 
 
@@ -302,7 +314,7 @@ class PackedConv:
         self.split = bool(split_precision)
         self.w = pack_conv_weight(weight.to(device), groups, self.split)
         self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
-        self.w_wino = self.w_wino2 = self.w_wino2q = self.w_wino1 = None
+        self.w_wino = self.w_wino2 = self.w_wino1 = None
         if (winograd1d and not self.split and not _fp32_depth and self.kh == 1 and self.kw in (3, 5, 7, 11) and stride == (1, 1)
                 and dilation[1] in ((1, 3, 5) if self.kw != 5 else (1,)) and padding == (0, (self.kw - 1) // 2 * dilation[1]) and self.padding_end is None
                 and groups == 1 and cin_g >= 16):
@@ -312,15 +324,21 @@ class PackedConv:
                 and padding == (1, 1) and self.padding_end is None and groups == 1 and cin_g >= 8):
             self.w_wino = pack_conv_weight(winograd_kernel(weight.detach().to(device=device, dtype=torch.float32)), 1, False)
             if winograd2d and self.cout % 48 == 0:
-                self.w_wino2 = winograd2d_image(weight.detach().to(device=device, dtype=torch.float32))
-                # the quad-fragment image (16/9 of the weights in HBM) is read only under the dev switch winograd2d_quads: built on first
-                # use from the caller's own weight tensor (a reference, normally host memory), never for the product's layers
-                self._wino2q_src, self._wino2q_dev = weight.detach(), device
+                # ONE image on the device: the one the routed kernel reads (_w2d_code()).  The other fragment layouts (16/9 of the weights
+                # in HBM each) exist only for the dev switches / A-B tools: built on first use from the caller's own weight tensor (a
+                # reference, normally host memory), never for the product's layers
+                self._wino2_src, self._wino2_dev, self._wino2_images = weight.detach(), device, {}
+                self.w_wino2 = self.wino2_image(_w2d_code()[1])
+
+    def wino2_image(self, kind):
+        """The F(2 x 2, 3 x 3) weight image with "dword" / "pairs" / "quads" fragments (winograd2d_image)."""
+        if kind not in self._wino2_images:
+            self._wino2_images[kind] = winograd2d_image(self._wino2_src.to(device=self._wino2_dev, dtype=torch.float32),
+                                                         quads=kind == "quads", pairs=kind == "pairs")
+        return self._wino2_images[kind]
 
     def wino2q(self):
-        if self.w_wino2q is None:
-            self.w_wino2q = winograd2d_image(self._wino2q_src.to(device=self._wino2q_dev, dtype=torch.float32), quads=True)
-        return self.w_wino2q
+        return self.wino2_image("quads")
 
     def out_hw(self, h, w):
         pe = self.padding if self.padding_end is None else self.padding_end
@@ -441,17 +459,20 @@ def conv(x, pc, res=None, out=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NON
     # (layers of fewer than 16 output channels -- the vocoder's conv_post, 32 -> 1 -- are one HBM pass: the streaming kernels keep them)
     wino1 = (winograd1d and getattr(pc, "w_wino1", None) is not None and pc.cout >= 16 and is1d and not shuffle and out_len is None and w % 4 == 0
              and n * w >= winograd1d_min_positions and pre_act in (ACT_NONE, ACT_LRELU) and 0.0 <= pre_slope <= 1.0
+             and not res_mul and w < (1 << 24) and x4.stride(1) < (1 << 24)      # what csrc/conv_g1w.h's conv_g1w_applicable() also demands
+             and 15 * (-(-(c // pc.groups) // 32) * 32) * (-(-pc.cout // 32) * 32) * 4 < (1 << 31)
              and x4.data_ptr() % 16 == 0 and x4.stride(0) % 4 == 0 and x4.stride(1) % 4 == 0 and x4.stride(1) >= w
              and o4.data_ptr() % 16 == 0 and o4.stride(0) % 4 == 0 and o4.stride(1) % 4 == 0
              and (r4 is None or (r4.data_ptr() % 16 == 0 and r4.stride(0) % 4 == 0 and r4.stride(1) % 4 == 0)))
     # 2 / 3: eight / four waves per workgroup; + 2: quad fragments
     d.gemm_tile = gemm_tile
-    d.wino = (winograd2d_code or (2 if winograd2d_waves == 8 else 3) + (2 if winograd2d_quads else 0)) if wino2 else 1 if wino else 8 if wino1 else 0
+    w2code, w2kind = _w2d_code()
+    d.wino = w2code if wino2 else 1 if wino else 8 if wino1 else 0
     prof = conv_profile
     if prof is not None and x.is_cuda:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _call("aicg_conv_forward", ctypes.addressof(d), _ptr(x4), _ptr((pc.wino2q() if winograd2d_quads else pc.w_wino2) if wino2 else pc.w_wino if wino else pc.w_wino1 if wino1 else pc.w), _ptr(b), _ptr(r4), _ptr(o4), _stream(x))
+    _call("aicg_conv_forward", ctypes.addressof(d), _ptr(x4), _ptr(pc.wino2_image(w2kind) if wino2 else pc.w_wino if wino else pc.w_wino1 if wino1 else pc.w), _ptr(b), _ptr(r4), _ptr(o4), _stream(x))
     if prof is not None and x.is_cuda:
         e1.record()
         prof.events.append((e0, e1))
@@ -759,6 +780,9 @@ class GruSegments:
         self.multi = bool(multi) and hidden == 256 and GRU_WORKGROUPS == 4     # the four-workgroup kernel; otherwise the single-workgroup one
         self.scratch = torch.empty(32 * hidden + 64, dtype=torch.uint8, device=gi.device) if self.multi else None
         self.done = 0
+        # the error word inside `scratch` is zeroed by the FIRST segment's launch (on the stream that launch runs on): until that launch
+        # has completed the word is uninitialised allocator memory, and timed_out() -- polled from another stream -- must not read it
+        self._first_done = None
 
     def run(self, s1):
         """Queue steps self.done .. s1 - 1."""
@@ -768,6 +792,9 @@ class GruSegments:
         if self.multi:
             _call("aicg_gru_bidir_4wg_seg", _ptr(self.gi), _ptr(self.whh_t), _ptr(self.bhh), _ptr(self.out), self.hidden, self.T, s0, s1,
                   _ptr(self.state), _ptr(self.scratch), _stream(self.gi))
+            if s0 == 0 and self.gi.is_cuda:
+                self._first_done = torch.cuda.Event()
+                self._first_done.record(torch.cuda.current_stream(self.gi.device))
             if s1 == self.T:   # one flag for the whole recurrence (the error word accumulates over the segments)
                 _gru_pending.append((self.scratch[32 * self.hidden: 32 * self.hidden + 4].view(torch.int32),
                                      (self.gi, self.whh_t, self.bhh, self.out, self.hidden)))
@@ -779,8 +806,14 @@ class GruSegments:
     def timed_out(self):
         """The recurrence's error word as of NOW (a 4-byte read on the current stream; the segments may still be running on another):
         nonzero = a partner exchange of the multi-workgroup kernel timed out, the output of that and every later segment is invalid
-        (later segments bail out early).  pipeline() polls it between chunks instead of synthesising a whole track from bad pitch."""
-        return bool(self.multi) and int(self.scratch[32 * self.hidden: 32 * self.hidden + 4].view(torch.int32).item()) != 0
+        (later segments bail out early).  pipeline() polls it between chunks instead of synthesising a whole track from bad pitch.
+        False while the first segment -- whose launch zeroes the word -- has not run to completion (nothing can have timed out yet, and
+        the word is not initialised before it: ADVICE r5)."""
+        if not self.multi or self.done == 0:
+            return False
+        if self._first_done is not None and not self._first_done.query():
+            return False
+        return int(self.scratch[32 * self.hidden: 32 * self.hidden + 4].view(torch.int32).item()) != 0
 
     def ready(self):
         """[lo, hi): frames whose forward AND backward state exist after the steps queued so far (empty: lo >= hi)."""

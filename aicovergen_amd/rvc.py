@@ -56,8 +56,16 @@ class Config:
         return preset
 
 
+def _placement(device):
+    """src/main.py:195 names 'cuda:0' outright and hands it to load_hubert / get_vc.  Under the host emulator of tests/ (the only
+    way this package runs without a GPU) every tensor lives in host memory."""
+    from . import _lib
+    return torch.device("cpu") if _lib.backend() == "emu" else device
+
+
 def load_hubert(device, is_half, model_path):
     """-> HuBERT content encoder in eval mode on `device` (src/rvc.py:98-109)."""
+    device = _placement(device)
     net = _hubert.HubertModel(_hubert.load_state(model_path)).to(device)
     net = net.half() if is_half else net.float()
     net.eval()
@@ -66,6 +74,7 @@ def load_hubert(device, is_half, model_path):
 
 def get_vc(device, is_half, config, model_path):
     """-> (checkpoint dict, version, synthesizer, target sample rate, VC pipeline object) (src/rvc.py:112-139)."""
+    device = _placement(device)
     cpt = torch.load(model_path, map_location="cpu")
     if not ("config" in cpt and "weight" in cpt):
         raise ValueError(f"Incorrect format for {model_path}. Use a voice model trained using RVC v2 instead.")

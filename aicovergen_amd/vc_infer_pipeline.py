@@ -94,7 +94,7 @@ class VC(object):
         self.t_center = self.sr * self.x_center
         self.t_max = self.sr * self.x_max
         self.device = config.device
-        self.rmvpe_path = os.path.join(BASE_DIR, 'rvc_models', 'rmvpe.pt')
+        self.rmvpe_path = None   # resolved on first use (_default_rmvpe_path), or set by the caller
 
     def get_optimal_torch_device(self, index: int = 0) -> torch.device:
         if torch.cuda.is_available():
@@ -166,10 +166,31 @@ class VC(object):
 
     _rmvpe_group = _f0_group
 
+    @staticmethod
+    def _default_rmvpe_path():
+        """Where rmvpe.pt lives.  The reference reads <its checkout>/rvc_models/rmvpe.pt (src/vc_infer_pipeline.py:18,327: BASE_DIR is the
+        parent of ITS src/); this module lives in another tree, so behind the shadow modules the file is looked up where main.py keeps its
+        models: the `rvc_models_dir` global of the running main module (src/main.py:27), then rvc_models/ beside every sys.path entry
+        (python src/main.py puts the reference's src/ there), then this repository's own rvc_models/."""
+        import sys
+        cands = []
+        for name in ("__main__", "main"):
+            d = getattr(sys.modules.get(name), "rvc_models_dir", None)
+            if isinstance(d, str):
+                cands.append(os.path.join(d, "rmvpe.pt"))
+        for q in sys.path:
+            if q:
+                cands.append(os.path.join(os.path.dirname(os.path.abspath(q)), "rvc_models", "rmvpe.pt"))
+        cands.append(os.path.join(BASE_DIR, "rvc_models", "rmvpe.pt"))
+        for c in cands:
+            if os.path.exists(c):
+                return c
+        return cands[-1]
+
     def _rmvpe(self):
         if not hasattr(self, "model_rmvpe"):
             from .rmvpe import RMVPE
-            self.model_rmvpe = RMVPE(self.rmvpe_path, is_half=self.is_half, device=self.device)
+            self.model_rmvpe = RMVPE(self.rmvpe_path or self._default_rmvpe_path(), is_half=self.is_half, device=self.device)
         return self.model_rmvpe
 
     def get_f0(self, input_audio_path, x, p_len, f0_up_key, f0_method, filter_radius, crepe_hop_length, inp_f0=None,
@@ -641,6 +662,10 @@ class VC(object):
             if ops.gru_timed_out() or f0_bad:
                 # the multi-workgroup recurrence starved of its partners (a busy or shared GPU): this rank's f0 is invalid.  Recompute
                 # it locally on the single-workgroup kernel (no collective: the other ranks may be fine) and redo this rank's chunks
+                import warnings
+                warnings.warn("aicovergen_amd: the multi-workgroup BiGRU timed out waiting for its partner workgroups (busy or shared GPU); "
+                              "f0 and this rank's chunks are recomputed on the single-workgroup kernel -- this call costs about twice "
+                              "its usual time", RuntimeWarning)
                 f0_host = self._rmvpe().infer_from_audio_device(audio_pad.float(), thred=0.03, two_workgroups=False).cpu().numpy()
                 pitch, pitchf = run_f0(f0_host)
                 many = self._vc_features_many(model, [audio_pad.float()[bounds[ci][0]:bounds[ci][1]] for ci in mine], index, big_npy,

@@ -336,12 +336,18 @@ def main():
             if rank == 0:
                 prof, sprof = ops.ConvProfile(), ops.StageProfile()
                 ops.conv_profile, ops.stage_profile = prof, sprof
+            from aicovergen_amd import dist as adist
+            adist.profile_joins = True          # the collectives' own time (device drained around each): this step only
             barrier()
             tp = time.perf_counter()
-            one_step(args.config, mdxs, vc, hub, net_g, wave44_dev, group, emu)
+            _, _, _, prof_split = one_step(args.config, mdxs, vc, hub, net_g, wave44_dev, group, emu)
             barrier()
             prof_ms = (time.perf_counter() - tp) * 1e3
+            adist.profile_joins = False
             ops.conv_profile = ops.stage_profile = None
+            for k, v in prof_split.items():
+                if k.endswith("allgather_s"):
+                    split[k] = v
     dts = torch.tensor([dt], dtype=torch.float64, device=device)
     per_rank = [dt]
     have_group = td.is_available() and td.is_initialized()
@@ -354,7 +360,8 @@ def main():
     # with the f0 branch underneath, the wait for f0 behind it, the chunk loop, the chunk join, post -- so that a scaling curve says
     # which term grew
     # (mdx_allgather_s, rvc_lengths_allgather_s, rvc_pieces_allgather_s: the collective alone, device drained on both sides --
-    #  RCCL time as opposed to waiting for the slowest rank, which is in the stage walls around it; `collectives` = how many ran)
+    #  RCCL time as opposed to waiting for the slowest rank, which is in the stage walls around it; measured in the ONE instrumented
+    #  step behind the timed region (dist.profile_joins), the timed steps only count them; `collectives` = how many ran per step)
     split_keys = ["mdx_s", "mdx_allgather_s", "plan_s", "f0_s", "f0_wait_s", "chunks_s", "join_s", "rvc_lengths_allgather_s",
                   "rvc_pieces_allgather_s", "post_s", "collectives"]
     per_rank_split = None

@@ -131,6 +131,10 @@ typedef struct aicg_conv_desc {
                                      [Cout / 48][ceil(Cin / 8)][s = 0..1][point p = 4 i + q][ks = 0..3][m = 0..47] floats with element
                                      U[48 mu + m][8 chunk + 4 s + ks][i][q], U = G g G^T, G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]
                                      (zero beyond Cin).  Needs Cout % 48 == 0, W % 4 == 0, x 16-byte aligned with strides % 4 == 0.
+                                     12: the same kernel reading PAIR fragments -- the image with the two points of a pair side by side,
+                                     [Cout / 48][ceil(Cin / 8)][s][p / 2][ks][m][p % 2]: one 8-byte LDS read per two MFMAs (round 6: 1-6 %
+                                     faster on the MDX-Net levels; what aicovergen_amd routes by default).  (3: four waves per
+                                     workgroup; 4 / 5: eight / four waves on QUAD fragments [s][p / 4][ks][m][p % 4].)
                                      8: the ONE-dimensional form F(2, 3) of a k = 3 / 7 / 11, stride 1, dilation 1, "same"-padded 1-D layer
                                      (csrc/conv_g1w.h: 4 / 10 / 15 instead of 6 / 14 / 22 contractions per output pair -- the vocoder's
                                      ResBlocks, src/infer_pack/modules.py:299-312); w_packed holds the packed images of the

@@ -97,9 +97,13 @@ def chunk_frames(n_samples):
     return 2 * ((n_samples - 400) // 320 + 1)
 
 
-def vc_pipeline(nets, geo, audio, f0_up_key=0, rms_mix_rate=0.25, protect=0.33, tgt_sr=40000, noise_seed=7, sid=0):
-    """VC.pipeline with f0_method='rmvpe', file_index='', if_f0=1, resample_sr=0 (vc_infer_pipeline.py:474-653).
-    Returns (int16 audio, dict of intermediates)."""
+def vc_pipeline(nets, geo, audio, f0_up_key=0, rms_mix_rate=0.25, protect=0.33, tgt_sr=40000, noise_seed=7, sid=0,
+                f0_method="rmvpe", crepe_hop=128, crepe_dither=None, f0_inject=None):
+    """VC.pipeline with file_index='', if_f0=1, resample_sr=0 (vc_infer_pipeline.py:474-653) and f0_method 'rmvpe' (get_f0 :346-353)
+    or 'mangio-crepe' (:296-301 -> get_f0_crepe_computation :96-137 on the padded track with p_len and crepe_hop_length; needs
+    nets["crepe_sd"]; `crepe_dither`: the cents offsets replacing torchcrepe's random dither, None = none).
+    `f0_inject`: an f0 track (Hz per 10 ms frame) that replaces the estimator's output in front of the key shift and the
+    quantiser -- for tests that hold f0 fixed.  Returns (int16 audio, dict of intermediates)."""
     cfg = nets["synth_cfg"]
     upp = 1
     for u in cfg[12]:
@@ -108,7 +112,16 @@ def vc_pipeline(nets, geo, audio, f0_up_key=0, rms_mix_rate=0.25, protect=0.33, 
     opt_ts = cut_points(geo, audio)
     audio_pad = np.pad(audio, (geo.t_pad, geo.t_pad), mode="reflect")
     p_len = audio_pad.shape[0] // geo.window
-    f0, hidden = orm.infer_from_audio(nets["rmvpe_sd"], audio_pad, 0.03)
+    hidden = bins = post = None
+    if f0_inject is not None:
+        f0 = np.asarray(f0_inject, dtype=np.float64).copy()
+    elif f0_method == "rmvpe":
+        f0, hidden = orm.infer_from_audio(nets["rmvpe_sd"], audio_pad, 0.03)
+    elif f0_method == "mangio-crepe":
+        from . import crepe as ocr
+        f0, bins, post = ocr.mangio_crepe_f0(nets["crepe_sd"], audio_pad, p_len, crepe_hop, dither=crepe_dither)
+    else:
+        raise ValueError(f0_method)
     coarse, f0bak = orm.f0_to_coarse(f0, f0_up_key)
     pitch = torch.tensor(coarse[:p_len]).unsqueeze(0).long()
     pitchf = torch.tensor(f0bak[:p_len]).unsqueeze(0).float()
@@ -135,4 +148,5 @@ def vc_pipeline(nets, geo, audio, f0_up_key=0, rms_mix_rate=0.25, protect=0.33, 
     if audio_max > 1:
         max_int16 /= audio_max
     return (audio_opt * max_int16).astype(np.int16), dict(opt_ts=opt_ts, f0=f0bak, coarse=coarse, float_audio=audio_opt,
-                                                           pre_rms=pre_rms, hidden=hidden)
+                                                           pre_rms=pre_rms, hidden=hidden, crepe_bins=bins, crepe_post=post,
+                                                           audio_pad=audio_pad, p_len=p_len)
