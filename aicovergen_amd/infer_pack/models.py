@@ -14,6 +14,7 @@ from collections import namedtuple
 
 import numpy as np
 import torch
+from .. import _env
 import torch.nn.functional as F
 
 from .. import ops
@@ -331,7 +332,7 @@ class _SynthesizerBase:
     def _rb_streams(self, device, nk):
         """Side streams for the ResBlock chains of a vocoder stage (one per chain but the first, created once per model: the caching
         allocator keeps a pool per stream), or None where the chains run one after the other (the default; CPU / emulator)."""
-        if device.type != "cuda" or nk < 2 or os.environ.get("AICG_RB_STREAMS", "0") != "1":
+        if device.type != "cuda" or nk < 2 or _env.dev("AICG_RB_STREAMS", "0") != "1":
             return None
         have = getattr(self, "_rb_side", None)
         if have is None or len(have) != nk - 1:

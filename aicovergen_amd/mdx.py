@@ -14,6 +14,7 @@ import os
 
 import numpy as np
 import torch
+from . import _env
 
 from . import audio_io, ops
 from .mdx_net import ConvTDFNet
@@ -81,7 +82,7 @@ class MDX:
     DEFAULT_CHUNK_SIZE = 0 * DEFAULT_SR
     DEFAULT_MARGIN_SIZE = 1 * DEFAULT_SR
     DEFAULT_PROCESSOR = 0
-    WINDOW_BATCH = int(os.environ.get("AICG_MDX_BATCH", "8"))  # windows per network launch
+    WINDOW_BATCH = int(_env.dev("AICG_MDX_BATCH", "8"))  # windows per network launch
 
     def __init__(self, model_path, params: MDXModel, processor=DEFAULT_PROCESSOR, state_dict=None):
         self.device = params.device if state_dict is not None else (

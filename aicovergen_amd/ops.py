@@ -9,6 +9,7 @@ import threading
 
 import numpy as np
 import torch
+from . import _env
 
 from . import _lib
 
@@ -218,7 +219,7 @@ def pack_conv_weight(w, groups=1, split=False):
 # Winograd F(2, 3) along rows for plain 3 x 3 layers (csrc/conv_ws3w.h): 12 instead of 18 MFMA contractions per output pair.  Layers
 # packed while this is set carry the transformed kernel next to the direct one; conv() takes it for large maps with a bias + none /
 # ReLU epilogue.  The f0 models (packed under fp32_layers()) never do: their goldens pin the direct summation order's bins.
-winograd = os.environ.get("AICG_WINOGRAD", "1") != "0"
+winograd = _env.dev("AICG_WINOGRAD", "1") != "0"
 winograd_min_positions = 32768   # below this the 64-column tiles (4 or 8 rows) do not fill the chip (tests lower it)
 
 
@@ -230,15 +231,15 @@ def winograd_kernel(w):
 
 # The two-dimensional form F(2 x 2, 3 x 3) (csrc/conv_w2d.h): 16 instead of 36 contractions per 2 x 2 output block, for layers whose
 # output channels come in units of 48 (every MDX-Net level).  AICG_WINOGRAD=1 keeps the row-only form everywhere.
-winograd2d = os.environ.get("AICG_WINOGRAD", "2") == "2"
-winograd2d_waves = int(os.environ.get("AICG_W2D_WAVES", "8"))   # 8: two waves per SIMD on an 8 x 64 tile; 4: one per SIMD on 4 x 64
+winograd2d = _env.dev("AICG_WINOGRAD", "2") == "2"
+winograd2d_waves = int(_env.dev("AICG_W2D_WAVES", "8"))   # 8: two waves per SIMD on an 8 x 64 tile; 4: one per SIMD on 4 x 64
 
 
-winograd2d_code = int(os.environ.get("AICG_W2D_CODE", "0"))       # tools: a schedule variant under test (aicg_conv_desc.wino 6 ..)
-winograd2d_quads = os.environ.get("AICG_W2D_QUADS", "0") == "1"   # fragment image: [s][p / 4][ks][m][p % 4] (16-byte fragments)
+winograd2d_code = int(_env.dev("AICG_W2D_CODE", "0"))       # tools: a schedule variant under test (aicg_conv_desc.wino 6 ..)
+winograd2d_quads = _env.dev("AICG_W2D_QUADS", "0") == "1"   # fragment image: [s][p / 4][ks][m][p % 4] (16-byte fragments)
 # the eight-wave form reads PAIR fragments ([s][p / 2][ks][m][p % 2], one ds_read_b64 per two MFMAs: aicg_conv_desc.wino 12) unless
 # AICG_W2D_PAIRS=0 (dword fragments, wino 2): 1-6 % faster on the five MDX-Net levels (profiles/r06_kbench_w2d_pairs.txt)
-winograd2d_pairs = os.environ.get("AICG_W2D_PAIRS", "1") != "0"
+winograd2d_pairs = _env.dev("AICG_W2D_PAIRS", "1") != "0"
 
 
 def _w2d_code():
@@ -269,8 +270,8 @@ def winograd2d_image(w, quads=False, pairs=False):
 # One-dimensional Winograd F(2, 3) for the vocoder's k = 3 / 7 / 11 ResBlock layers, dilation 1 / 3 / 5 (csrc/conv_g1w.h): 4 / 10 / 15 products
 # per output pair and input channel instead of 6 / 14 / 22.  Layers packed while this is set carry the slot image next to the direct one;
 # conv() takes it where the kernel applies (aligned rows, W % 4 == 0, enough positions).  The f0 models never do (fp32_layers()).
-winograd1d = os.environ.get("AICG_WINOGRAD1D", "1") != "0"
-winograd1d_min_positions = int(os.environ.get("AICG_WINOGRAD1D_MIN", "16384"))
+winograd1d = _env.dev("AICG_WINOGRAD1D", "1") != "0"
+winograd1d_min_positions = int(_env.dev("AICG_WINOGRAD1D_MIN", "16384"))
 
 
 def winograd1d_kernel(w):
@@ -700,8 +701,8 @@ def avgpool2x2(x):
     return out
 
 
-GRU_TWO_WORKGROUPS = os.environ.get("AICG_GRU_2WG", "1") != "0"     # "0": the single-workgroup kernel (no co-residency needed)
-GRU_WORKGROUPS = int(os.environ.get("AICG_GRU_WG", "4"))             # workgroups per direction of the multi-workgroup form: 4 or 2
+GRU_TWO_WORKGROUPS = _env.dev("AICG_GRU_2WG", "1") != "0"     # "0": the single-workgroup kernel (no co-residency needed)
+GRU_WORKGROUPS = int(_env.dev("AICG_GRU_WG", "4"))             # workgroups per direction of the multi-workgroup form: 4 or 2
 
 
 _gru_pending = []

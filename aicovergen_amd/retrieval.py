@@ -35,6 +35,7 @@ import struct
 
 import numpy as np
 import torch
+from . import _env
 
 from . import ops
 
@@ -52,7 +53,7 @@ class FeatureIndex:
         self.ntotal, self.dim = self.big.shape
         self.device = device
         if exact is None:
-            exact = os.environ.get("AICG_KNN", "").lower() == "exact"
+            exact = _env.dev("AICG_KNN", "").lower() == "exact"
         self.ivf = lists is not None and not exact
         self.labels = None                                         # storage position -> faiss label (None: identity)
         if lists is not None:

@@ -14,6 +14,7 @@ from time import time as ttime
 
 import numpy as np
 import torch
+from . import _env
 import torch.nn.functional as F
 from scipy import signal
 
@@ -358,7 +359,7 @@ class VC(object):
             a = audio.detach().to(dev).double().view(-1)
         else:
             a = torch.from_numpy(np.ascontiguousarray(audio, dtype=np.float64)).to(dev)
-        if os.environ.get("AICG_FILTFILT", "device") == "host" or a.numel() <= 3 * max(len(ah), len(bh)):
+        if _env.dev("AICG_FILTFILT", "device") == "host" or a.numel() <= 3 * max(len(ah), len(bh)):
             audio = torch.from_numpy(np.ascontiguousarray(signal.filtfilt(bh, ah, a.cpu().numpy()))).to(dev)
         else:
             audio = ops.filtfilt_f64(a, bh, ah)
@@ -417,7 +418,7 @@ class VC(object):
         index = big_npy = None
         if file_index != "" and os.path.exists(file_index) and index_rate != 0:
             try:
-                if os.environ.get("AICG_GPU_KNN", "1") != "0":
+                if _env.dev("AICG_GPU_KNN", "1") != "0":
                     from . import retrieval
                     index = retrieval.load_index(file_index, self.device)   # vectors in HBM, search + mix on the device
                 else:
@@ -462,10 +463,10 @@ class VC(object):
         #  "1" = the recurrence as one launch.)  One rank on a GPU takes the progressive schedule too since the f0 chain became the
         #  longer branch of the phase (r4: HuBERT 74.9 ms, f0 79.4): the chunk loop then starts when HuBERT is done, on the middle chunks,
         #  while the recurrence finishes the track's ends -- 718.7 -> 713.9 ms per 240 s track at 8 segments (4: 715.5, 16: 715.6).
-        env_seg = int(os.environ.get("AICG_F0_SEGMENTS", "0"))
+        env_seg = int(_env.dev("AICG_F0_SEGMENTS", "0"))
         nseg = env_seg or (16 if world > 1 else (8 if on_gpu else 0))
         overlap = (if_f0 == 1 and f0_method == "rmvpe" and (on_gpu or nseg > 1)
-                   and os.environ.get("AICG_OVERLAP_F0", "1") != "0")
+                   and _env.dev("AICG_OVERLAP_F0", "1") != "0")
         feats_of = {}
         f0_wait = 0.0
         gru_seg = None        # progressive f0: the recurrence's handle (its exchange-timeout word is polled between chunks)
@@ -481,7 +482,7 @@ class VC(object):
                 # high priority: the f0 branch is a short U-Net followed by a 70 ms recurrence on four CUs; dispatched first it
                 # leaves the chip to HuBERT while the GRU runs, dispatched behind HuBERT's launches it finishes 40 ms later
                 # (AICG_F0_PRIORITY=0: default priority)
-                prio = -1 if os.environ.get("AICG_F0_PRIORITY", "1") != "0" else 0
+                prio = -1 if _env.dev("AICG_F0_PRIORITY", "1") != "0" else 0
                 side = self._f0_stream = torch.cuda.Stream(device=self.device, priority=prio)
             # one upload of the padded track: a pageable host->device copy on the default stream waits for the whole device,
             # side stream included, so the chunk loop below must not issue any
@@ -585,7 +586,7 @@ class VC(object):
         # profiles/r05_timeline.json: 6.5 + 6.1 ms at two chunk boundaries, the first vocoder behind TWO encoder halves).  What that
         # buys is small -- 2 ms per 240 s track: short launches running beside the vocoder cost it nearly what they take alone
         # (one stream: 674.7 ms, two: 667) -- and a stream priority changes nothing.  AICG_OVERLAP_SYNTH=0: one stream.
-        two_streams = overlap and on_gpu and hasattr(net_g, "infer_front") and os.environ.get("AICG_OVERLAP_SYNTH", "1") != "0"
+        two_streams = overlap and on_gpu and hasattr(net_g, "infer_front") and _env.dev("AICG_OVERLAP_SYNTH", "1") != "0"
         fronts = {}
         if two_streams:
             main = torch.cuda.current_stream(self.device)

@@ -12,6 +12,8 @@ import sys
 import pytest
 import torch
 
+os.environ.setdefault("AICG_DEV", "1")   # tests pin kernel forms and schedules against each other: the development switches are live (aicovergen_amd/_env.py)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -46,7 +48,8 @@ def _bind(kind):
         if _emu_path is None:
             sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
             import build_emu
-            _emu_path = build_emu.build_emu()
+            # AICG_EMU_SANITIZE=1 (tests/emu/run_sanitized.sh): the AddressSanitizer + UBSan build of the emulator
+            _emu_path = build_emu.build_emu(sanitize=os.environ.get("AICG_EMU_SANITIZE") == "1")
         _lib._use_library_for_tests(_emu_path, "emu")
     else:
         if not torch.cuda.is_available():

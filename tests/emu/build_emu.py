@@ -15,7 +15,34 @@ OBJ = os.path.join(HERE, "build")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 
-def build_emu(force=False):
+ASAN_RT = None
+
+
+def asan_runtime():
+    """The AddressSanitizer runtime a python process must LD_PRELOAD to load the sanitized emulator."""
+    r = subprocess.run([CLANG, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True)
+    path = r.stdout.strip()
+    if not os.path.isabs(path) or not os.path.exists(path):
+        raise RuntimeError("no AddressSanitizer runtime next to " + CLANG)
+    return path
+
+
+def build_emu(force=False, sanitize=False):
+    """sanitize=True: tests/emu/libaicg_emu_asan.so, the same sources under -fsanitize=address,undefined: every kernel's
+    indexing runs on the host, where an out-of-bounds LDS or global access lands in a red zone -- dynamic LDS is an exact-size
+    allocation in that build, global buffers are torch's (malloc, intercepted).  Run with tests/emu/run_sanitized.sh."""
+    global OUT, OBJ
+    if sanitize:
+        old = OUT, OBJ
+        OUT, OBJ = os.path.join(HERE, "libaicg_emu_asan.so"), os.path.join(HERE, "build_asan")
+        try:
+            return _build(force, True)
+        finally:
+            OUT, OBJ = old
+    return _build(force, False)
+
+
+def _build(force, sanitize):
     if not os.path.exists(CLANG):
         raise RuntimeError("host clang++ not found at " + CLANG)
     os.makedirs(OBJ, exist_ok=True)
@@ -24,6 +51,10 @@ def build_emu(force=False):
         glob.glob(os.path.join(HERE, "include", "hip", "*.h"))
     flags = ["-x", "c++", "-std=c++17", "-O2", "-g", "-fPIC", "-I", os.path.join(HERE, "include"),
              "-Wno-unused-value", "-Wno-unknown-attributes", "-DAICG_DEV_SWITCHES", "-ffp-contract=fast-honor-pragmas", "-mfma"]  # hipcc's default contraction mode for device code
+    san = ["-fsanitize=address,undefined", "-fno-sanitize=vptr,function", "-fno-omit-frame-pointer", "-shared-libsan"] if sanitize else []
+    flags = flags + san
+    if sanitize:
+        flags[flags.index("-O2")] = "-O1"
     jobs, objs = [], []
     newest_hdr = max(os.path.getmtime(h) for h in hdrs)
     for s in srcs:
@@ -41,7 +72,7 @@ def build_emu(force=False):
             if rc != 0:
                 raise RuntimeError("emu compile failed: %s\n%s" % (" ".join(cmd), log))
     if jobs or not os.path.exists(OUT):
-        cmd = [CLANG, "-shared", "-fPIC", "-o", OUT] + objs + ["-lpthread"]
+        cmd = [CLANG, "-shared", "-fPIC", "-o", OUT] + san + objs + ["-lpthread"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("emu link failed:\n" + r.stdout + r.stderr)
@@ -49,4 +80,4 @@ def build_emu(force=False):
 
 
 if __name__ == "__main__":
-    print(build_emu(force="--force" in sys.argv))
+    print(build_emu(force="--force" in sys.argv, sanitize="--sanitize" in sys.argv))

@@ -8,6 +8,17 @@
 #include <thread>
 #include <vector>
 
+// AddressSanitizer build (tests/emu/build_emu.py sanitize=True): the fibers' stack switches are announced to the sanitizer, and a launch's
+// dynamic LDS is an allocation of EXACTLY the requested size (red zones right behind it) instead of a reused, larger one.
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define EMU_ASAN 1
+#endif
+#endif
+#ifdef EMU_ASAN
+#include <sanitizer/common_interface_defs.h>
+#endif
+
 extern "C" void emu_ctx_switch(void** from_sp, void* to_sp);
 asm(R"(
 .text
@@ -47,6 +58,8 @@ struct Fiber {
     int flat;
     Wave* wave;
     bool done;
+    void* fake;          // EMU_ASAN: the sanitizer's fake-stack handle of this fiber while it is switched out
+    const void* bottom;  // EMU_ASAN: lowest address of the fiber's stack
 };
 struct Block {
     Fiber fib[kMaxThreads];
@@ -72,7 +85,13 @@ void* wave_slot(int lane) { return cur->wave->slots[lane]; }
 static void switch_to(Fiber* f) {
     Fiber* prev = cur;
     cur = f;
+#ifdef EMU_ASAN
+    __sanitizer_start_switch_fiber(prev->done ? nullptr : &prev->fake, f->bottom, kStack);
+#endif
     emu_ctx_switch(&prev->sp, f->sp);
+#ifdef EMU_ASAN
+    __sanitizer_finish_switch_fiber(prev->fake, nullptr, nullptr);     // (back on `prev`)
+#endif
 }
 
 static void die(const char* msg) {
@@ -127,8 +146,20 @@ void wave_barrier() {
     while (w->gen == g) yield_wave();
 }
 
+#ifdef EMU_ASAN
+thread_local const void* tl_main_bottom = nullptr;
+thread_local size_t tl_main_size = 0;
+#endif
+
 static void fiber_main() {
     Block* b = tl_blk;
+#ifdef EMU_ASAN
+    {   // first time on this stack; whoever switched here came either from the OS thread's stack (its bounds are remembered) or a fiber's
+        const void* ob; size_t os;
+        __sanitizer_finish_switch_fiber(nullptr, &ob, &os);
+        if (cur->flat == 0) { tl_main_bottom = ob; tl_main_size = os; }
+    }
+#endif
     (*b->body)();
     Fiber* me = cur;
     me->done = true;
@@ -144,6 +175,9 @@ static void fiber_main() {
     // last one out: back to the OS thread
     void* dummy;
     cur = nullptr;
+#ifdef EMU_ASAN
+    __sanitizer_start_switch_fiber(nullptr, tl_main_bottom, tl_main_size);
+#endif
     emu_ctx_switch(&dummy, b->main_sp);
     die("unreachable");
 }
@@ -170,11 +204,18 @@ static Block* get_block_ctx(size_t shmem) {
         blk->dyn = nullptr;
         blk->dyn_cap = 0;
     }
+#ifdef EMU_ASAN
+    // exactly `shmem` bytes ending at the allocation's end: an LDS access past the size the launch asked for lands in a red zone
+    free(blk->dyn);
+    blk->dyn = shmem ? (char*)aligned_alloc(16, (shmem + 15) / 16 * 16) : nullptr;
+    blk->dyn_cap = shmem;
+#else
     if (shmem > blk->dyn_cap) {
         free(blk->dyn);
         blk->dyn = (char*)aligned_alloc(64, (shmem + 63) / 64 * 64);
         blk->dyn_cap = shmem;
     }
+#endif
     return blk;
 }
 
@@ -198,6 +239,8 @@ static void run_block(Block* b, dim3 bidx, dim3 block, size_t shmem, const std::
         f.tid = dim3(i % block.x, (i / block.x) % block.y, i / (block.x * block.y));
         f.wave = &b->waves[i / 64];
         f.done = false;
+        f.fake = nullptr;
+        f.bottom = b->stacks + (size_t)i * kStack;
         uintptr_t top = (uintptr_t)(b->stacks + (size_t)(i + 1) * kStack);
         top &= ~(uintptr_t)15;
         void** sp = (void**)top;
@@ -207,7 +250,14 @@ static void run_block(Block* b, dim3 bidx, dim3 block, size_t shmem, const std::
         f.sp = sp;
     }
     cur = &b->fib[0];
+#ifdef EMU_ASAN
+    void* main_fake = nullptr;
+    __sanitizer_start_switch_fiber(&main_fake, b->fib[0].bottom, kStack);
+#endif
     emu_ctx_switch(&b->main_sp, b->fib[0].sp);
+#ifdef EMU_ASAN
+    __sanitizer_finish_switch_fiber(main_fake, nullptr, nullptr);
+#endif
     cur = nullptr;
 }
 

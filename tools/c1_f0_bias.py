@@ -24,6 +24,7 @@ difference| as measured -- that turns the spread into quantiles of the waveform 
 """
 import json
 import os
+os.environ.setdefault("AICG_DEV", "1")   # development switches are live in tools (aicovergen_amd/_env.py)
 import sys
 
 import numpy as np

@@ -1,6 +1,7 @@
 """BASELINE C1 (30 s through VC.pipeline, full-size networks) against the reference's own output: waveform relative RMS / LSB rates
 and the f0 track's distance to the reference's, in one line -- for A/B runs over the AICG_* switches (GPU box)."""
 import os, sys, numpy as np, torch
+os.environ.setdefault("AICG_DEV", "1")   # development switches are live in tools (aicovergen_amd/_env.py)
 sys.path.insert(0, "tests"); sys.path.insert(0, ".")
 import conftest
 conftest._bind("hip")

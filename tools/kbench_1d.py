@@ -1,5 +1,6 @@
 """1-D conv micro-benchmark (vocoder ResBlock / HuBERT / enc_p shapes); A/B through the AICG_CONV_* env switches."""
 import os, sys, torch
+os.environ.setdefault("AICG_DEV", "1")   # development switches are live in tools (aicovergen_amd/_env.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from aicovergen_amd import ops  # noqa: E402
 dev = torch.device("cuda:0")

@@ -1,5 +1,6 @@
 """2-D conv micro-benchmark on the GPU box (MDX-Net TFC / RMVPE levels); A/B through the AICG_CONV_* env switches."""
 import os
+os.environ.setdefault("AICG_DEV", "1")   # development switches are live in tools (aicovergen_amd/_env.py)
 import sys
 
 import torch

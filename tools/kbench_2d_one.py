@@ -1,5 +1,6 @@
 """One 2-D conv shape: ci co k N H W; A/B through the AICG_* env switches (AICG_PRECISION=bf16x3 for the split kernels)."""
 import os, sys, torch
+os.environ.setdefault("AICG_DEV", "1")   # development switches are live in tools (aicovergen_amd/_env.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from aicovergen_amd import ops  # noqa: E402
 dev = torch.device("cuda:0")

@@ -1,5 +1,6 @@
 """A/B of conv tile variants on vocoder shapes (AICG_CONV_8WAVE=0/1 set by the caller)."""
 import os, sys, torch
+os.environ.setdefault("AICG_DEV", "1")   # development switches are live in tools (aicovergen_amd/_env.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from aicovergen_amd import ops
 dev = torch.device("cuda:0")

@@ -1,6 +1,7 @@
 """Attention variants A/B (dev library, AICG_ATTN_VAR of attn.hip): HuBERT (12 x 64, T = 3300) and enc_p (2 x 96, T = 6600, window 10).
 The switch is read once per process: one child per (variant, round); rounds interleave the variants (the shader clock sags over a run)."""
 import os, sys, subprocess, torch
+os.environ.setdefault("AICG_DEV", "1")   # development switches are live in tools (aicovergen_amd/_env.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 VARS = [("r3 registers (2 / 1 waves per SIMD)", 8), ("3 / 2 waves per SIMD", 0), ("+ exp2", 1), ("+ lazy rescale", 2), ("+ both", 3),
         ("4 / 3 waves per SIMD (spills)", 4), ("4 / 3 waves + both", 7)]

@@ -1,6 +1,7 @@
 """The vocoder's 256-channel ResBlock layers (73 080 positions: 2 x 571 tiles of 128 x 128 = 2.2 rounds over 512 slots) under a forced tile
 height (dev library, AICG_CONV_FORCE_BM; one child per setting)."""
 import os, sys, subprocess, torch
+os.environ.setdefault("AICG_DEV", "1")   # development switches are live in tools (aicovergen_amd/_env.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 if "BM_CHILD" not in os.environ:
     for bm in (sys.argv[1:] or ["0", "64", "96", "0"]):

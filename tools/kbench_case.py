@@ -1,5 +1,6 @@
 """Time one 2-D conv shape: kbench_case.py n ci co H W k"""
 import os, sys, torch
+os.environ.setdefault("AICG_DEV", "1")   # development switches are live in tools (aicovergen_amd/_env.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from aicovergen_amd import ops  # noqa: E402

@@ -3,6 +3,7 @@
 aicg_conv_desc.gemm_tile: 1 = conv_ws3, 12 / 13 = the 128 x 256 / 64 x 256 tile of conv_g1k (development library only:
 AICG_LIB=dev), 0 = the library's policy."""
 import os, sys, statistics, torch
+os.environ.setdefault("AICG_DEV", "1")   # development switches are live in tools (aicovergen_amd/_env.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from aicovergen_amd import _lib, ops  # noqa: E402
 dev = torch.device("cuda:0")

@@ -1,5 +1,6 @@
 """HuBERT's per-token GEMMs as 1 x 1 convolutions over the (C, T) map of a rank's chunks (T = 13198): tile choice A/B (dev library)."""
 import os, sys, torch
+os.environ.setdefault("AICG_DEV", "1")   # development switches are live in tools (aicovergen_amd/_env.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from aicovergen_amd import _lib, ops  # noqa: E402
 if os.environ.get("AICG_LIB"):

@@ -1,6 +1,7 @@
 """HuBERT's per-token GEMMs (1 x 1 convolutions over a (C, T) map): what the rate depends on -- row alignment of T, tile height,
 fragment form (dev library switches; one child per setting, the switches are read once per process)."""
 import os, sys, subprocess, torch
+os.environ.setdefault("AICG_DEV", "1")   # development switches are live in tools (aicovergen_amd/_env.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 SETS = [("default T=13198", {}, 13198), ("T=13200 (rows 16-byte aligned)", {}, 13200), ("T=13312 (= 104 x 128)", {}, 13312),
         ("64-row tiles", {"AICG_CONV_FORCE_BM": "64"}, 13198), ("4-byte fragments (conv_ws)", {"AICG_CONV_V3": "0"}, 13198),

@@ -1,5 +1,6 @@
 """LayerNorm over channels of (1, 768, T): the batched-HuBERT shape (T = 13198) and the per-chunk one (T = 3300)."""
 import os, sys, torch
+os.environ.setdefault("AICG_DEV", "1")   # development switches are live in tools (aicovergen_amd/_env.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from aicovergen_amd import _lib, ops  # noqa: E402
 if os.environ.get("AICG_LIB"):

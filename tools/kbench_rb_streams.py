@@ -1,6 +1,7 @@
 """The vocoder's ResBlock chains on their own streams (AICG_RB_STREAMS=1, opt-in) against the one-stream walk, round-robin on the bench track's
 RVC stage (VC.pipeline: HuBERT || f0 phase, then per chunk front + vocoder) and on one reference-sized synthesizer chunk."""
 import os, sys, time, statistics, torch
+os.environ.setdefault("AICG_DEV", "1")   # development switches are live in tools (aicovergen_amd/_env.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from synthetic.inputs import vocal_like  # noqa: E402

@@ -1,5 +1,6 @@
 """HuBERT feature-extractor layer (512 -> 512, k = 3, stride 2) on a rank's chunks: ablation of conv_ws3 (dev library, AICG_CONV_ABLATE)."""
 import os, sys, subprocess, torch
+os.environ.setdefault("AICG_DEV", "1")   # development switches are live in tools (aicovergen_amd/_env.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 NAMES = [("full", 0), ("no x loads", 256), ("no w loads", 512), ("no loads", 768), ("no MFMA loop", 8), ("no epilogue", 16), ("stride 1 (same output count)", -1)]
 if "ABL" not in os.environ:

@@ -1,5 +1,6 @@
 """TDF (time-distributed fully connected) GEMMs of the MDX-Net U-Net levels, batch 16: f -> f/8 -> f with BN + ReLU (+ residual)."""
 import os, sys, torch
+os.environ.setdefault("AICG_DEV", "1")   # development switches are live in tools (aicovergen_amd/_env.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from aicovergen_amd import ops, _lib  # noqa: E402
 if os.environ.get("AICG_LIB"):

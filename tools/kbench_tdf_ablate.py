@@ -3,6 +3,7 @@ AICG_TDF_ABLATE = bits: 1 no residual loads, 2 no output stores, 4 no phase-2 we
 32 no phase-2 MFMAs, 64 no phase-1 MFMAs).  One variant per process (the switch is read once):
     for a in 0 1 2 3 4 7 8 16 24 31 32 64 96 0; do AICG_TDF_ABLATE=$a python tools/kbench_tdf_ablate.py; done"""
 import os, sys, torch
+os.environ.setdefault("AICG_DEV", "1")   # development switches are live in tools (aicovergen_amd/_env.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from aicovergen_amd import _lib, ops  # noqa: E402
 _lib._use_library_for_tests(os.path.join(ROOT, "aicovergen_amd", "libaicg_hip_dev.so"), "hip")

@@ -1,6 +1,7 @@
 """MDX-Net TFC 3 x 3 layers (batch 16): direct implicit GEMM vs Winograd F(2, 3) along rows (conv_ws3w.h) vs the two-dimensional
 F(2 x 2, 3 x 3) kernel (conv_w2d.h) in its eight- and four-wave forms; error of each against the direct kernel and torch (corner map)."""
 import os, sys, torch
+os.environ.setdefault("AICG_DEV", "1")   # development switches are live in tools (aicovergen_amd/_env.py)
 import torch.nn.functional as F
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from aicovergen_amd import _lib, ops  # noqa: E402

@@ -1,6 +1,7 @@
 """RMVPE's deep 3x3 layers (few positions, long K) under the dispatcher's fill target AICG_CONV_WANT (dev library; default 512 workgroups:
 below it the tile shrinks).  One child per setting (the switch is read once per process)."""
 import os, sys, subprocess, torch
+os.environ.setdefault("AICG_DEV", "1")   # development switches are live in tools (aicovergen_amd/_env.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 if "WANT_CHILD" not in os.environ:
     for want in (sys.argv[1:] or ["512", "256", "128", "64"]):

@@ -1,5 +1,6 @@
 """MDX-Net TFC 3 x 3 layers (batch 16): Winograd F(2, 3)-along-rows kernel (conv_ws3w.h) against the direct implicit GEMM."""
 import os, sys, torch
+os.environ.setdefault("AICG_DEV", "1")   # development switches are live in tools (aicovergen_amd/_env.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from aicovergen_amd import _lib, ops  # noqa: E402
 if os.environ.get("AICG_LIB"):

@@ -1,5 +1,6 @@
 """Where a Winograd stage's time goes (dev library: AICG_CONV_ABLATE bits of conv_ws3w.h) on the MDX level-1 TFC layer."""
 import os, sys, torch
+os.environ.setdefault("AICG_DEV", "1")   # development switches are live in tools (aicovergen_amd/_env.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from aicovergen_amd import _lib, ops  # noqa: E402
 _lib._use_library_for_tests(os.path.join(ROOT, "aicovergen_amd", "libaicg_hip_dev.so"), "hip")

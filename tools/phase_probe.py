@@ -1,6 +1,7 @@
 """Where the HuBERT || f0 phase of VC.pipeline goes on the bench track: the phase as shipped, each branch alone (AICG_OVERLAP_F0=0),
 and the phase with attention / with the HuBERT GEMMs' time removed (upper bounds of what those kernels can still give)."""
 import os, sys, time, torch, numpy as np
+os.environ.setdefault("AICG_DEV", "1")   # development switches are live in tools (aicovergen_amd/_env.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from aicovergen_amd import ops  # noqa: E402

@@ -2,6 +2,7 @@
 cut over time (1 632 frames, 816 per rank + 320 of context), against the single-process run.  Expected output: both ranks equal,
 and equal to the single process (r2: bit-identical int16)."""
 import os, sys, numpy as np, torch, torch.distributed as td, torch.multiprocessing as mp
+os.environ.setdefault("AICG_DEV", "1")   # development switches are live in tools (aicovergen_amd/_env.py)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def work(rank, world, port, q):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
