@@ -205,6 +205,7 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
             if (d->wino == 7) return run_w2d_ablation(p, st2, 1024);   // patch pieces from one L2-resident KiB (wrong results)
             if (d->wino == 9) return run_w2d_ablation(p, st2, 2048);   // no patch pieces at all (wrong results)
             if (d->wino == 10) return run_w2d_ablation(p, st2, 1);     // no DMA at all (wrong results)
+            if (d->wino == 13) return run_w2d_pairs_ablation(p, st2, 8192);   // pair fragments, place() at the top of the stage that needs it
 #endif
             // 12: eight waves on the PAIR-fragment image ([s][p / 2][ks][m][p % 2]: one 8-byte fragment read per two MFMAs)
             const int rc = d->wino == 2 ? run_w2d_8(p, st2) : d->wino == 3 ? run_w2d_4(p, st2) : d->wino == 4 ? run_w2d_8q(p, st2)

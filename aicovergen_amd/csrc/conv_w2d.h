@@ -161,7 +161,7 @@ __device__ inline T w2d_opaque(T v) {   // a per-item copy of a uniform value th
 // fragments -- [s][p / 2][ks][m][p % 2], one ds_read_b64 per two MFMAs.
 // ABL: profiling variants, instantiated in the dev library only (tools/kbench_w2d_ablate.py): 1 no DMA, 2 no fragment reads, 4 no patch
 // reads / transform, 8 no MFMAs, 16 no epilogue, 32 no stage barriers, 64 clocks of workgroup 0 into y[0..1], 128 epilogue without its
-// stores, 512 the round-4 / 5 stage burst (one w2d_dma16 per piece, pieces w, w + NW, ... of the patch) for A/B against the runs of
+// stores, 8192 place() at the top of the stage that needs it, 512 the round-4 / 5 stage burst (one w2d_dma16 per piece, pieces w, w + NW, ... of the patch) for A/B against the runs of
 // w2d_dma_run.  Compile-time: a run-time switch in the k-step loop costs the 8-wave form its register budget.
 template <int NW, int PF, int ABL = 0>
 __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
@@ -249,10 +249,19 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
             else tl[(NPP + e) * NT] = ok ? 4u * (unsigned)(c * (int)p.x_sc + hin * (int)p.x_sh + win) : kBufOob;
         }
     };
+    // place() ahead of time: a stage whose burst will open a new item places it BEHIND its first k-step of the stage before -- ~80 scalar
+    // and ~100 vector instructions (divisions, range checks) that stood at the top of a stage, where all eight waves run them with the
+    // matrix pipe idle; behind a k-step the SIMD's other wave covers them
+    bool placed = false;
+    auto place_ahead = [&]() __attribute__((always_inline)) {
+        if constexpr (OLD_DMA || (ABL & 8192) != 0) return;      // (ABL 8192: at the top of the stage, as in rounds 4-5)
+        if (li < my_items && lc == 0 && !placed) { place(first + slot + li * slots); placed = true; }
+    };
     auto issue = [&](float* buf) __attribute__((always_inline)) {   // the next stage of the walk = (item li, chunk lc) into `buf`: one burst
         if (li >= my_items) return;
         if constexpr ((dbg & 1) != 0) { if (++lc == nchunk) { lc = 0; ++li; } return; }
-        if (lc == 0) place(first + slot + li * slots);
+        if (lc == 0 && !placed) place(first + slot + li * slots);
+        placed = false;
         const int lane = lane_now();
         const long wbase = ((long)lmu * nchunk + lc) * kW2dWFloats;
         const BufRsrc wb = make_buf(p.w3 + wbase, (unsigned)(kW2dWFloats * 4));
@@ -499,6 +508,9 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
         if constexpr (FIRST) open_kstep(b_cur);
         kstep(first_tag, std::true_type{}, b_cur, 0, b_cur, 1);
         if constexpr (FIRST) issue(b_fill);
+        // (steady stages only: with more than three chunks per item that is where the cursor wraps; an item's first and last stages keep
+        //  their register budgets -- behind the last stage's first k-step the placement's temporaries pushed accumulators through scratch)
+        if constexpr (!FIRST && !LAST) place_ahead();
         stamp();
         if constexpr (LAST) kstep(std::false_type{}, std::false_type{}, b_cur, 1, b_nxt, 0);
         else kstep(std::false_type{}, std::true_type{}, b_cur, 1, b_nxt, 0);
@@ -623,6 +635,7 @@ int run_w2d_4(ConvArgs& p, hipStream_t st);
 int run_w2d_8q(ConvArgs& p, hipStream_t st);
 int run_w2d_8p(ConvArgs& p, hipStream_t st);   // eight waves on PAIR fragments (image [s][p / 2][ks][m][p % 2])
 int run_w2d_4q(ConvArgs& p, hipStream_t st);
-int run_w2d_ablation(ConvArgs& p, hipStream_t st, int bits);   // dev library only: the 8-wave form with ABL = bits (1 = unknown variant)
+int run_w2d_ablation(ConvArgs& p, hipStream_t st, int bits);
+int run_w2d_pairs_ablation(ConvArgs& p, hipStream_t st, int bits);   // dev library only: the pair-fragment form with ABL = bits   // dev library only: the 8-wave form with ABL = bits (1 = unknown variant)
 
 }  // namespace aicg

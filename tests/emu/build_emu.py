@@ -28,13 +28,15 @@ def asan_runtime():
 
 
 def build_emu(force=False, sanitize=False):
-    """sanitize=True: tests/emu/libaicg_emu_asan.so, the same sources under -fsanitize=address,undefined: every kernel's
+    """sanitize=True: $AICG_EMU_ASAN_DIR/libaicg_emu_asan.so (default /tmp/aicg_emu_asan), the same sources under -fsanitize=address,undefined: every kernel's
     indexing runs on the host, where an out-of-bounds LDS or global access lands in a red zone -- dynamic LDS is an exact-size
     allocation in that build, global buffers are torch's (malloc, intercepted).  Run with tests/emu/run_sanitized.sh."""
     global OUT, OBJ
     if sanitize:
         old = OUT, OBJ
-        OUT, OBJ = os.path.join(HERE, "libaicg_emu_asan.so"), os.path.join(HERE, "build_asan")
+        # outside the repository (the sanitized objects are ~0.5 GB: they must not travel with gpurun snapshots)
+        d = os.environ.get("AICG_EMU_ASAN_DIR", "/tmp/aicg_emu_asan")
+        OUT, OBJ = os.path.join(d, "libaicg_emu_asan.so"), os.path.join(d, "build")
         try:
             return _build(force, True)
         finally:
