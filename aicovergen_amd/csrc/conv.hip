@@ -207,9 +207,10 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
             if (d->wino == 10) return run_w2d_ablation(p, st2, 1);     // no DMA at all (wrong results)
             if (d->wino == 13) return run_w2d_pairs_ablation(p, st2, 8192);   // pair fragments, place() at the top of the stage that needs it
 #endif
+            // 16 (development builds): four waves on pair fragments with 4-channel stages -- two workgroups per CU;
             // 12: eight waves on the PAIR-fragment image ([s][p / 2][ks][m][p % 2]: one 8-byte fragment read per two MFMAs)
             const int rc = d->wino == 2 ? run_w2d_8(p, st2) : d->wino == 3 ? run_w2d_4(p, st2) : d->wino == 4 ? run_w2d_8q(p, st2)
-                         : d->wino == 12 ? run_w2d_8p(p, st2) : run_w2d_4q(p, st2);
+                         : d->wino == 12 ? run_w2d_8p(p, st2) : d->wino == 16 ? run_w2d_4p2(p, st2) : run_w2d_4q(p, st2);
             if (rc == 1)
                 return fail(AICG_E_ARG, "aicg_conv_forward: wino 2 needs Cout %% 48 == 0, W %% 4 == 0, 16-byte aligned x with strides %% 4 == 0");
             return rc;

@@ -163,8 +163,15 @@ __device__ inline T w2d_opaque(T v) {   // a per-item copy of a uniform value th
 // reads / transform, 8 no MFMAs, 16 no epilogue, 32 no stage barriers, 64 clocks of workgroup 0 into y[0..1], 128 epilogue without its
 // stores, 8192 place() at the top of the stage that needs it, 512 the round-4 / 5 stage burst (one w2d_dma16 per piece, pieces w, w + NW, ... of the patch) for A/B against the runs of
 // w2d_dma_run.  Compile-time: a run-time switch in the k-step loop costs the 8-wave form its register budget.
-template <int NW, int PF, int ABL = 0>
-__global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
+// KS: k-steps per LDS stage.  2 (routed): stages of 8 input channels.  1 (development builds, aicg_conv_desc.wino 16): stages of 4 -- half
+// the weights slab (12 KiB) and four patch planes per stage, three stage buffers in < 64 KiB, so that TWO four-wave workgroups fit a CU
+// (each SIMD holds one wave of each) and what one workgroup cannot hide -- its barriers, its bursts, an item's epilogue and pipeline
+// restart -- could run under the other's MFMAs.  Compiles to 256 registers without a spill, bit-identical output -- and runs level for
+// level as fast as the eight-wave form, 2.42 / 2.16 / 1.18 / 0.52 / 0.22 ms against 2.42 / 2.15 / 1.17 / 0.52 / 0.22, with or without a start
+// skew of half an item between the two workgroups of a CU (profiles/r06_kbench_w2d_two_workgroups*.txt): exposed synchronisation is not
+// what the kernel waits for.
+template <int NW, int PF, int ABL = 0, int KS = 2>
+__global__ void __launch_bounds__(64 * NW, KS == 1 ? 2 : 1) conv_w2d_kernel(ConvArgs p) {
     constexpr int dbg = ABL;
     constexpr bool OLD_DMA = (ABL & 512) != 0;
     constexpr int BUFS = 3;                          // stage g computes, stage g + 1 has landed (k-step (g, 1) reads ahead into it), stage g + 2 is being filled
@@ -179,9 +186,13 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
     constexpr int NT = 64 * NW;
     constexpr int PROWS = NW + 2;                                 // patch rows
     constexpr int PLANEQ = w2d_plane_quads(NW);
-    constexpr int STAGE = w2d_stage_floats(NW);
-    constexpr int PPIECES = 8 * PLANEQ / 64;                      // DMA pieces of patch per chunk (23 / 15)
-    static_assert(8 * PLANEQ % 64 == 0 && kW2dWPieces % NW == 0, "pieces are whole");
+    constexpr int CHS = 4 * KS;                                   // input channels per stage
+    constexpr int WFLOATS = kW2dWFloats * KS / 2;                 // floats of weights per stage
+    constexpr int WPIECES = WFLOATS / 256;
+    constexpr int PPIECES = (CHS * PLANEQ + 63) / 64;             // DMA pieces of patch per stage (23 / 15; KS 1: the last one may be ragged)
+    constexpr int STAGE = WFLOATS + PPIECES * 256;
+    static_assert(WPIECES % NW == 0 && (KS == 1 || CHS * PLANEQ % 64 == 0), "pieces are whole");
+    static_assert(KS == 2 || KS == 1, "one or two k-steps per stage");
     HIP_DYNAMIC_SHARED(float4, smem4)
     float* const smem = reinterpret_cast<float*>(smem4);
     float* const bias_s = smem + BUFS * STAGE;       // Cout: the layer's bias
@@ -218,7 +229,7 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
     // ---- DMA plan of this wave: weight pieces w WPW .. + WPW - 1, patch pieces w, w + NW, ...  What a lane fetches of a patch piece --
     // quad (channel c, patch row, quad column) -- is the same for every tile: decoded once into LDS (c << 16 | row << 8 | column, or ~0
     // for an unused slot); per item the byte offsets are rebuilt from it, again into LDS ([piece][thread] dwords behind the bias).
-    constexpr int WPW = kW2dWPieces / NW;            // weight pieces per wave (3 / 6)
+    constexpr int WPW = WPIECES / NW;                // weight pieces per wave (3 / 6; KS 1, four waves: 3)
     constexpr int NPP = (PPIECES + NW - 1) / NW;     // patch pieces per wave (3 / 4)
     unsigned* const tab_s = reinterpret_cast<unsigned*>(bias_s + ((nmu * kW2dM + 3) & ~3));   // [2][NPP][NT]: decode, then offsets
 #pragma unroll
@@ -227,7 +238,7 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
         const int Q = piece * 64 + (tid & 63);
         const int c = Q / PLANEQ, rem = Q - c * PLANEQ;
         const int row = rem / kW2dPQuads, qd = rem - row * kW2dPQuads;
-        tab_s[e * NT + tid] = (piece < PPIECES && rem < PROWS * kW2dPQuads) ? (unsigned)(c << 16 | row << 8 | qd) : 0xffffffffu;
+        tab_s[e * NT + tid] = (piece < PPIECES && c < CHS && rem < PROWS * kW2dPQuads) ? (unsigned)(c << 16 | row << 8 | qd) : 0xffffffffu;
     }
     const float* xg = p.x;
     int li = 0, lc = 0, lmu = 0;                     // DMA cursor: item of this workgroup, chunk; M unit of that item
@@ -263,10 +274,11 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
         if (lc == 0 && !placed) place(first + slot + li * slots);
         placed = false;
         const int lane = lane_now();
-        const long wbase = ((long)lmu * nchunk + lc) * kW2dWFloats;
-        const BufRsrc wb = make_buf(p.w3 + wbase, (unsigned)(kW2dWFloats * 4));
-        const long left = (long)(p.Cin_g - lc * 8) * p.x_sc * 4;   // bytes up to the end of the image's channels: absent channels read 0
-        const BufRsrc xb = make_buf(xg + (long)lc * 8 * p.x_sc, (unsigned)lmin(left, 0x7fffffffL));
+        // (the image is [M unit][8-channel chunk][k-step] slabs: with KS == 1 a stage is one k-step's half slab, `nchunk` counts those)
+        const long wbase = ((long)lmu * nchunk + lc) * WFLOATS;
+        const BufRsrc wb = make_buf(p.w3 + wbase, (unsigned)(WFLOATS * 4));
+        const long left = (long)(p.Cin_g - lc * CHS) * p.x_sc * 4;   // bytes up to the end of the image's channels: absent channels read 0
+        const BufRsrc xb = make_buf(xg + (long)lc * CHS * p.x_sc, (unsigned)lmin(left, 0x7fffffffL));
         if constexpr (OLD_DMA) {
 #pragma unroll
             for (int e = 0; e < WPW; ++e) {
@@ -277,7 +289,7 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
 #pragma unroll
             for (int e = 0; e < NPP; ++e) {
                 const int piece = wave + NW * e;
-                if (piece < PPIECES) w2d_dma16(xb, tl[e * NT], 0u, buf + kW2dWFloats + piece * 256, lane);
+                if (piece < PPIECES) w2d_dma16(xb, tl[e * NT], 0u, buf + WFLOATS + piece * 256, lane);
             }
         } else {
             // the stage buffer's LDS byte address as scalar arithmetic on the workgroup's LDS base (no generic-to-LDS cast per piece)
@@ -294,8 +306,8 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
                 w2d_dma_run<3, true>(wb, wv, 1024u * (unsigned)(wave * WPW + 3), buf + (wave * WPW + 3) * 256,
                                      buf_lds + 1024u * (unsigned)(wave * WPW + 3), lane);
             // this wave's patch pieces wave NPP .. + NPP - 1 (the last wave may own fewer: PPIECES is not a multiple of NW)
-            float* pdst = buf + kW2dWFloats + wave * NPP * 256;
-            const unsigned pdst_lds = buf_lds + (unsigned)(kW2dWFloats * 4) + 1024u * (unsigned)(wave * NPP);
+            float* pdst = buf + WFLOATS + wave * NPP * 256;
+            const unsigned pdst_lds = buf_lds + (unsigned)(WFLOATS * 4) + 1024u * (unsigned)(wave * NPP);
             const int mine_p = PPIECES - wave * NPP;          // >= NPP except on the last wave
             if constexpr ((dbg & 2048) != 0) { (void)pdst; (void)pdst_lds; (void)mine_p; }   // ABL 2048: weights only (wrong results)
             else if (mine_p >= NPP) w2d_dma_run<NPP, false>(xb, po, 0u, pdst, pdst_lds, lane);
@@ -329,7 +341,7 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
     lane_offsets();
     auto load_raw = [&](const float* stage, int s, int r0, int r1) __attribute__((always_inline)) {   // patch rows r0 .. r1 - 1 of k-step s of the stage at `stage`
         // (stage buffers are 16-byte aligned and every term of the index is a whole float2: 8-byte reads)
-        const float2* pl = reinterpret_cast<const float2*>(__builtin_assume_aligned(stage + kW2dWFloats, 16)) + p_lane2 + s * 4 * PLANEQ * 2;
+        const float2* pl = reinterpret_cast<const float2*>(__builtin_assume_aligned(stage + WFLOATS, 16)) + p_lane2 + s * 4 * PLANEQ * 2;
 #pragma unroll
         for (int r = r0; r < r1; ++r)
 #pragma unroll
@@ -506,6 +518,18 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
         lane_offsets();
         stamp();
         if constexpr (FIRST) open_kstep(b_cur);
+        if constexpr (KS == 1) {
+            // one k-step per stage: it prepares the NEXT stage's (landed: the barrier above), except an item's last
+            if constexpr (LAST) kstep(first_tag, std::false_type{}, b_cur, 0, b_nxt, 0);
+            else kstep(first_tag, std::true_type{}, b_cur, 0, b_nxt, 0);
+            if constexpr (FIRST) issue(b_fill);
+            if constexpr (!FIRST && !LAST) place_ahead();
+            stamp();
+            w2d_dma_wait();
+            stamp();
+            float* t1 = b_cur; b_cur = b_nxt; b_nxt = b_fill; b_fill = t1;
+            return;
+        }
         kstep(first_tag, std::true_type{}, b_cur, 0, b_cur, 1);
         if constexpr (FIRST) issue(b_fill);
         // (steady stages only: with more than three chunks per item that is where the cursor wraps; an item's first and last stages keep
@@ -608,7 +632,7 @@ __global__ void __launch_bounds__(64 * NW) conv_w2d_kernel(ConvArgs p) {
 
 // returns 0 launched, < 0 error, 1 not applicable.  p.w3 must point at the F(2 x 2, 3 x 3) image of ops.winograd2d_image:
 // [Cout / 48][ceil(Cin / 8)][s = 0..1][point 0..15][ks = 0..3][m = 0..47], element = U[48 mu + m][8 chunk + 4 s + ks][point].
-template <int NW, int PF, int ABL = 0>
+template <int NW, int PF, int ABL = 0, int KS = 2>
 static int launch_conv_w2d(ConvArgs& p, hipStream_t stream) {
     constexpr int BUFS = 3;
     auto al4 = [](long v) { return (v & 3) == 0; };
@@ -616,24 +640,26 @@ static int launch_conv_w2d(ConvArgs& p, hipStream_t stream) {
     if ((long)8 * p.x_sc + (long)p.H * p.x_sh >= (1L << 29)) return 1;   // 32-bit byte offsets inside an 8-channel slab
     p.tiles_w = idiv_up(p.Wo, kW2dCols);
     p.tiles_h = idiv_up(p.Ho, NW);
-    p.nchunk = idiv_up(p.Cin_g, 8);
+    p.nchunk = idiv_up(p.Cin_g, 8) * (KS == 1 ? 2 : 1);     // stages per item (KS 1: the second half of a ragged last chunk is zero weights)
     p.Mpad = p.Cout_g / kW2dM;
     const long nitems = (long)p.N * p.tiles_h * p.tiles_w * p.Mpad;
     if (nitems > 2147483647L - 8) return fail(AICG_E_SHAPE, "conv: too many output tiles");
-    const size_t lds = (size_t)(BUFS * w2d_stage_floats(NW) + ((p.Cout_g + 3) & ~3) + 2 * ((w2d_plane_quads(NW) * 8 / 64 + NW - 1) / NW) * 64 * NW) * sizeof(float);   // stages, bias, DMA decode + offsets
-    if (lds > 160 * 1024) return 1;
+    constexpr int PP = (4 * KS * w2d_plane_quads(NW) + 63) / 64;     // patch pieces per stage
+    const size_t lds = (size_t)(BUFS * (kW2dWFloats * KS / 2 + PP * 256) + ((p.Cout_g + 3) & ~3) + 2 * ((PP + NW - 1) / NW) * 64 * NW) * sizeof(float);   // stages, bias, DMA decode + offsets
+    if (lds > (KS == 1 ? 80 : 160) * 1024) return 1;
     const int per_xcd = (int)((nitems + 7) >> 3);
-    int slots = 32;                                   // one workgroup per CU
+    int slots = KS == 1 ? 64 : 32;                    // workgroups per XCD: one per CU (KS 1: two)
     if (slots > per_xcd) slots = per_xcd;
-    allow_dynamic_lds((const void*)conv_w2d_kernel<NW, PF, ABL>, lds);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_w2d_kernel<NW, PF, ABL>), dim3((unsigned)(8 * slots)), dim3(64 * NW), lds, stream, p);
+    allow_dynamic_lds((const void*)conv_w2d_kernel<NW, PF, ABL, KS>, lds);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_w2d_kernel<NW, PF, ABL, KS>), dim3((unsigned)(8 * slots)), dim3(64 * NW), lds, stream, p);
     return check_launch("conv_w2d_kernel");
 }
 
 int run_w2d_8(ConvArgs& p, hipStream_t st);
 int run_w2d_4(ConvArgs& p, hipStream_t st);
 int run_w2d_8q(ConvArgs& p, hipStream_t st);
-int run_w2d_8p(ConvArgs& p, hipStream_t st);   // eight waves on PAIR fragments (image [s][p / 2][ks][m][p % 2])
+int run_w2d_8p(ConvArgs& p, hipStream_t st);
+int run_w2d_4p2(ConvArgs& p, hipStream_t st);  // four waves, pair fragments, 4-channel stages: two workgroups per CU   // eight waves on PAIR fragments (image [s][p / 2][ks][m][p % 2])
 int run_w2d_4q(ConvArgs& p, hipStream_t st);
 int run_w2d_ablation(ConvArgs& p, hipStream_t st, int bits);
 int run_w2d_pairs_ablation(ConvArgs& p, hipStream_t st, int bits);   // dev library only: the pair-fragment form with ABL = bits   // dev library only: the 8-wave form with ABL = bits (1 = unknown variant)
