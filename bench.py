@@ -150,7 +150,7 @@ def pmc_traffic_per_launch():
     """HBM bytes per conv launch from the committed rocprofv3 PMC passes of this same command (profiles/r03_summary.json, falling
     back to earlier rounds): FETCH_SIZE (x 2: the gfx950 under-report for wide reads, MI355X_MICROARCH.md) + WRITE_SIZE, KiB units, summed
     over the conv kernels; None when no summary is committed.  The counters cannot be collected inside the timed run."""
-    for tag in ("r05", "r04", "r03", "r02", "r01"):
+    for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
         path = os.path.join(ROOT, "profiles", "%s_summary.json" % tag)
         try:
             s = json.load(open(path))
