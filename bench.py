@@ -435,6 +435,16 @@ def main():
                 "algorithmic_tflop_per_step": conv["flops"] / 1e12,
                 "algorithmic_bytes_per_launch": conv["bytes"] / max(1, conv["launches"]),
                 "kernel_ms_per_step": conv["ms"]}
+            # the DOMINANT kernel of the step on its own: conv_w2d (Winograd F(2x2,3x3): MDX-Net's 3x3 layers; it executes 16 of the direct
+            # form's 36 multiply-adds), from the same live HIP events -- what profiles/rNN_summary.json states from the rocprofv3 trace
+            w2 = [r for r in prof.by_shape() if r["shape"].endswith(" wino2")]
+            if w2:
+                w2_ms, w2_gf, w2_n = sum(r["ms"] for r in w2), sum(r["gflop"] for r in w2), sum(r["launches"] for r in w2)
+                res["roofline"]["dominant_kernel"] = {
+                    "kernel": "conv_w2d_kernel (Winograd F(2x2,3x3), fp32 MFMA 16x16x4, pair fragments)", "launches_per_step": w2_n,
+                    "ms_per_step": w2_ms, "share_of_step": w2_ms / ms, "achieved": w2_gf / w2_ms, "executed": w2_gf / w2_ms * 16.0 / 36.0,
+                    "peak": MFMA_PEAK, "unit": "TFLOP/s", "frac": w2_gf / w2_ms * 16.0 / 36.0 / MFMA_PEAK,
+                    "note": "achieved = direct-form flops / event time; executed = 16/36 of them; frac = executed / peak"}
             res["stages"] = stage_table(conv, sprof.summary(), 1)
             if args.conv_shapes:
                 with open(args.conv_shapes, "w") as f:
