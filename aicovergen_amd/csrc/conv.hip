@@ -194,8 +194,8 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
             // 2: eight waves (two per SIMD) on an 8 x 64 tile; 3: four waves (one per SIMD) on a 4 x 64 tile; 4 / 5: the same with the
             // quad-fragment image ([s][p / 4][ks][m][p % 4]: one 16-byte fragment read per four MFMAs)
             hipStream_t st2 = (hipStream_t)stream;
-            if (w2d_ablate && d->wino == 2) {
-                const int ra = run_w2d_ablation(p, st2, (int)w2d_ablate);
+            if (w2d_ablate && (d->wino == 2 || d->wino == 12)) {
+                const int ra = d->wino == 2 ? run_w2d_ablation(p, st2, (int)w2d_ablate) : run_w2d_pairs_ablation(p, st2, (int)w2d_ablate);
                 if (ra != 1) return ra;
                 return fail(AICG_E_ARG, "aicg_conv_forward: AICG_CONV_ABLATE=%ld is not an instantiated variant of conv_w2d (or not the dev library)", (long)w2d_ablate);
             }
@@ -205,6 +205,7 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
             if (d->wino == 7) return run_w2d_ablation(p, st2, 1024);   // patch pieces from one L2-resident KiB (wrong results)
             if (d->wino == 9) return run_w2d_ablation(p, st2, 2048);   // no patch pieces at all (wrong results)
             if (d->wino == 10) return run_w2d_ablation(p, st2, 1);     // no DMA at all (wrong results)
+            if (d->wino == 14) return run_w2d_pairs_ablation(p, st2, 16384);  // pair fragments, MFMAs through the builtin (untied destinations: accumulator quads through scratch memory)
             if (d->wino == 13) return run_w2d_pairs_ablation(p, st2, 8192);   // pair fragments, place() at the top of the stage that needs it
 #endif
             // 16 (development builds): four waves on pair fragments with 4-channel stages -- two workgroups per CU;

@@ -148,6 +148,37 @@ __device__ __forceinline__ void w2d_fence() {
     __builtin_amdgcn_sched_barrier(0);
 #endif
 }
+// One MFMA of the k-step pipeline, accumulating IN PLACE.  TIED: inline asm whose "+v" operand pins the destination to the addend.  With
+// the builtin hipcc is free to give v_mfma a destination other than its addend, and in the straight-line k-steps around the steady loop
+// (an item's first stage behind its zero-started k-step, its whole last stage) it does -- it uses the MFMA to move accumulator quads into
+// the positions the next region wants -- at the price of both copies being live at once: the 192 accumulators + 64 registers of the
+// eight-wave form then do not fit and accumulator quads go through scratch memory inside the MFMA stream (s_nop 9 + scratch_store per
+// quad, a vmcnt(0) in front of the reload that also waits for the epilogue's stores).  The hazard recogniser does not see inside inline
+// asm: the only non-MFMA readers of an accumulator are the epilogue's VALU instructions, behind w2d_mfma_settle().
+template <bool TIED>
+__device__ __forceinline__ void w2d_mfma_acc(w2d_f32x4& c, float a, float b) {
+#ifdef AICG_EMULATED
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#else
+    if constexpr (TIED) asm("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    else c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#endif
+}
+template <bool TIED>
+__device__ __forceinline__ void w2d_mfma_zero(w2d_f32x4& c, float a, float b) {   // an item's first k-step: the addend is the inline constant 0
+#ifdef AICG_EMULATED
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, w2d_f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#else
+    if constexpr (TIED) asm("v_mfma_f32_16x16x4_f32 %0, %1, %2, 0" : "=&v"(c) : "v"(a), "v"(b));
+    else c = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, w2d_f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#endif
+}
+// an 8-pass MFMA's result may be read by a VALU / VMEM instruction 11 wait states after it issued (hipcc inserts them for the builtin)
+__device__ __forceinline__ void w2d_mfma_settle() {
+#ifndef AICG_EMULATED
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+#endif
+}
 template <class T>
 __device__ inline T w2d_opaque(T v) {   // a per-item copy of a uniform value the optimiser cannot hoist out of the walk
 #ifndef AICG_EMULATED
@@ -174,6 +205,7 @@ template <int NW, int PF, int ABL = 0, int KS = 2>
 __global__ void __launch_bounds__(64 * NW, KS == 1 ? 2 : 1) conv_w2d_kernel(ConvArgs p) {
     constexpr int dbg = ABL;
     constexpr bool OLD_DMA = (ABL & 512) != 0;
+    constexpr bool TIED = (ABL & 16384) == 0;         // MFMAs through inline asm with the destination tied to the addend (w2d_mfma_acc); ABL 16384: the builtin, for A/B
     constexpr int BUFS = 3;                          // stage g computes, stage g + 1 has landed (k-step (g, 1) reads ahead into it), stage g + 2 is being filled
     static_assert(PF == 0 || PF == 1 || PF == 2 || PF == 3, "PF 1 / 3: a fragment ring of PF + 1 slots (16 points are a whole number of turns); 0 / 2: groups");
     // PF == 0 / 2: GROUP fragments -- the weights of G = 4 / 2 consecutive points side by side in LDS ([s][p / G][ks][m][p % G]): one
@@ -419,11 +451,8 @@ __global__ void __launch_bounds__(64 * NW, KS == 1 ? 2 : 1) conv_w2d_kernel(Conv
                     if constexpr (G == 4) av = p4 == 0 ? aq[rb].x : p4 == 1 ? aq[rb].y : p4 == 2 ? aq[rb].z : aq[rb].w;
                     else av = p4 == 0 ? ap[rb].x : ap[rb].y;
                     if constexpr ((dbg & 8) != 0) { if constexpr (FIRST) acc[pt][rb] = w2d_f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
-                    if constexpr (FIRST) {
-                        acc[pt][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, V[pt], w2d_f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                    } else {
-                        acc[pt][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, V[pt], acc[pt][rb], 0, 0, 0);
-                    }
+                    if constexpr (FIRST) w2d_mfma_zero<TIED>(acc[pt][rb], av, V[pt]);
+                    else w2d_mfma_acc<TIED>(acc[pt][rb], av, V[pt]);
                 }
                 w2d_fence();
                 if (pg < NG - 1) fetch_q(cur, s, pg + 1, rb);
@@ -452,11 +481,8 @@ __global__ void __launch_bounds__(64 * NW, KS == 1 ? 2 : 1) conv_w2d_kernel(Conv
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) {
                 if constexpr ((dbg & 8) != 0) { if constexpr (FIRST) acc[pt][rb] = w2d_f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
-                if constexpr (FIRST) {
-                    acc[pt][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[pt & PF][rb], V[pt], w2d_f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                } else {
-                    acc[pt][rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ring[pt & PF][rb], V[pt], acc[pt][rb], 0, 0, 0);
-                }
+                if constexpr (FIRST) w2d_mfma_zero<TIED>(acc[pt][rb], ring[pt & PF][rb], V[pt]);
+                else w2d_mfma_acc<TIED>(acc[pt][rb], ring[pt & PF][rb], V[pt]);
             }
             w2d_fence();
         }
@@ -559,6 +585,7 @@ __global__ void __launch_bounds__(64 * NW, KS == 1 ? 2 : 1) conv_w2d_kernel(Conv
         // of both blocks -- four consecutive columns, one 16-byte store --, the odd lane the lower row: 12 stores per lane and item
         // instead of 24, each wave instruction eight 128-byte runs.
         if constexpr ((dbg & 16) != 0) continue;
+        if constexpr (TIED) w2d_mfma_settle();
         w2d_fence();   // the epilogue's index arithmetic stays out of the last k-step (scheduled into it, it pushed accumulators into scratch memory)
         const int tw_i = tile % p.tiles_w, th_i = (tile / p.tiles_w) % p.tiles_h, n = tile / (p.tiles_w * p.tiles_h);
         const int ho = th_i * NW + 2 * (wave >> 1), wo = tw_i * kW2dCols + 2 * (16 * (wave & 1) + l15);

@@ -25,14 +25,7 @@ int run_w2d_ablation(ConvArgs& p, hipStream_t st, int bits) {
         default: return 1;
     }
 }
-int run_w2d_pairs_ablation(ConvArgs& p, hipStream_t st, int bits) {
-    switch (bits) {
-        case 8192: return launch_conv_w2d<8, 2, 8192>(p, st);
-        default: return 1;
-    }
-}
 #else
 int run_w2d_ablation(ConvArgs&, hipStream_t, int) { return 1; }
-int run_w2d_pairs_ablation(ConvArgs&, hipStream_t, int) { return 1; }
 #endif
 }  // namespace aicg

@@ -123,7 +123,7 @@ def test_conv2d_winograd_rows(dev, monkeypatch, n, ci, co, H, W, act):
     assert rel_rms(y, ref + r) < 1e-5
 
 
-@pytest.mark.parametrize("waves,quads", [(8, False), (4, False), (8, True), (4, True), (8, "pairs"), (4, "pairs2")])
+@pytest.mark.parametrize("waves,quads", [(8, False), (4, False), (8, True), (4, True), (8, "pairs"), (4, "pairs2"), (8, "untied")])
 @pytest.mark.parametrize("n,ci,co,H,W,act", [(1, 8, 48, 8, 64, ops.ACT_RELU), (2, 16, 48, 11, 72, ops.ACT_NONE), (1, 24, 96, 5, 132, ops.ACT_RELU),
                                               (1, 12, 48, 17, 60, ops.ACT_RELU), (3, 40, 144, 3, 8, ops.ACT_NONE), (1, 48, 48, 16, 196, ops.ACT_RELU)])
 def test_conv2d_winograd_2d(dev, monkeypatch, waves, quads, n, ci, co, H, W, act):
@@ -132,7 +132,7 @@ def test_conv2d_winograd_2d(dev, monkeypatch, waves, quads, n, ci, co, H, W, act
     (a row pair whose second row does not exist), ragged and sub-tile widths (multiples of 4), several tiles per workgroup in the
     persistent walk, several images, output written into a channel slice.  Same products up to the exact 1/2 and 1/4 of G g G^T; the
     sums of the transformed operands round differently from the direct form, hence 2e-6 rather than bit equality."""
-    if quads == "pairs2" and dev.kind == "hip":
+    if quads in ("pairs2", "untied") and dev.kind == "hip":
         from aicovergen_amd import _lib
         if not _lib.get_path().endswith("_dev.so"):
             pytest.skip("the two-workgroups-per-CU form of conv_w2d (wino 16: measured level with the routed one) is compiled into development builds only")
@@ -143,9 +143,10 @@ def test_conv2d_winograd_2d(dev, monkeypatch, waves, quads, n, ci, co, H, W, act
     # "pairs": [s][p / 2][ks][m][p % 2], one 8-byte read per two MFMAs (aicg_conv_desc.wino 12: the routed default of the eight-wave form)
     # "pairs2": four waves, pair fragments, stages of FOUR input channels (one k-step each): two workgroups per CU (wino 16)
     monkeypatch.setattr(ops, "winograd2d_pairs", quads == "pairs")
-    monkeypatch.setattr(ops, "winograd2d_code", 16 if quads == "pairs2" else 0)
+    # "untied": the pair form with its MFMAs through the builtin instead of inline asm with the destination tied to the addend (wino 14, development builds)
+    monkeypatch.setattr(ops, "winograd2d_code", 16 if quads == "pairs2" else 14 if quads == "untied" else 0)
     assert ops._w2d_code() == {(8, False): (2, "dword"), (4, False): (3, "dword"), (8, True): (4, "quads"), (4, True): (5, "quads"),
-                               (8, "pairs"): (12, "pairs"), (4, "pairs2"): (16, "pairs")}[(waves, quads)]
+                               (8, "pairs"): (12, "pairs"), (4, "pairs2"): (16, "pairs"), (8, "untied"): (14, "pairs")}[(waves, quads)]
     torch.manual_seed(H * W + ci)
     x = torch.randn(n, ci, H, W)
     w = torch.randn(co, ci, 3, 3) * 0.1

@@ -6,7 +6,7 @@ from aicovergen_amd import _lib, ops  # noqa: E402
 _lib._use_library_for_tests(os.path.join(ROOT, "aicovergen_amd", "libaicg_hip_dev.so"), "hip")
 dev = torch.device("cuda:0")
 c, t, f = (int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (48, 256, 3072)))
-NAMES = [("full", 0), ("timeline", 256), ("full + clock", 64), ("no epilogue", 16), ("epilogue without stores", 128), ("no DMA", 1), ("no fragment reads", 2),
+NAMES = [("full", 0), ("builtin MFMAs (untied)", 16384), ("timeline", 256), ("full + clock", 64), ("no epilogue", 16), ("epilogue without stores", 128), ("no DMA", 1), ("no fragment reads", 2),
          ("no patch reads / transform", 4), ("no MFMA", 8), ("no barriers (wrong results)", 32),
          ("MFMA + fragment reads only", 1 | 4 | 16 | 32), ("MFMA only", 1 | 2 | 4 | 16 | 32), ("MFMA only + clock", 1 | 2 | 4 | 16 | 32 | 64),
          ("DMA + barriers only", 2 | 4 | 8 | 16), ("no DMA, no epilogue", 1 | 16), ("no LDS reads at all (fragments, patch)", 2 | 4)]
