@@ -138,7 +138,9 @@ __device__ __forceinline__ void w2d_dma_run(const BufRsrc& r, const unsigned (&v
 #undef W2D_BUMP
 #endif
 }
+template <bool SKIP = false>
 __device__ __forceinline__ void w2d_dma_wait() {
+    if constexpr (SKIP) return;                      // (ABL 32768: what the stage-end wait costs; races, wrong results)
 #ifndef AICG_EMULATED
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -513,11 +515,20 @@ __global__ void __launch_bounds__(64 * NW, KS == 1 ? 2 : 1) conv_w2d_kernel(Conv
     long long clk0 = 0, wall0 = 0;
     if constexpr ((dbg & (64 | 256)) != 0) { clk0 = clock64(); wall0 = wall_clock64(); }
 #endif
-    int tr_n = 2;
-    auto stamp = [&]() __attribute__((always_inline)) {                             // ABL bit 256: this wave's timeline (workgroup 0, thread 0) into y[2 ..]
+    // ABL bit 256: where wave 0 of workgroup 0 spends its cycles, per PHASE, summed in registers and written once at the end (the round-5
+    // form stored a time stamp per event: VMEM stores in the same in-order queue as the DMA pieces, which is what its "3 000-cycle
+    // burst" measured).  Phases: 0 barrier, 1 burst + lane offsets (+ open_kstep in an item's first stage), 2 k-step 0 (+ a first stage's
+    // burst / a steady stage's placement behind it), 3 k-step 1, 4 DMA wait, 5 epilogue
+    long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
+#ifndef AICG_EMULATED
+    if constexpr ((dbg & 256) != 0) tlast = clock64();
+#endif
+    auto stamp = [&](auto phase_tag) __attribute__((always_inline)) {
 #ifndef AICG_EMULATED
         if constexpr ((dbg & 256) != 0) {
-            if (blockIdx.x == 0 && tid == 0 && tr_n < 8192) p.y[tr_n++] = (float)(clock64() - clk0);
+            const long long t = clock64();
+            tph[decltype(phase_tag)::value] += t - tlast;
+            tlast = t;
         }
 #endif
     };
@@ -529,10 +540,9 @@ __global__ void __launch_bounds__(64 * NW, KS == 1 ? 2 : 1) conv_w2d_kernel(Conv
     auto stage = [&](auto first_tag, auto last_tag) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_tag)::value;
         constexpr bool LAST = decltype(last_tag)::value;
-        stamp();
         if (!first_stage && (dbg & 32) == 0) lds_barrier();
         first_stage = false;
-        stamp();
+        stamp(std::integral_constant<int, 0>{});
         // (an item's first stage issues its DMA BEHIND the first k-step: hipcc guards the registers the epilogue's stores read with a
         // vmcnt(0) in front of the first MFMA that overwrites them, which must meet those stores only, not DMA pieces issued a moment ago)
         // The stage's DMA goes out as one burst per wave at the top of the stage.  (Measured alternatives, DESIGN 2.9: one piece at a time
@@ -542,31 +552,36 @@ __global__ void __launch_bounds__(64 * NW, KS == 1 ? 2 : 1) conv_w2d_kernel(Conv
         // overwrites them, which must meet those stores only, not DMA pieces issued a moment ago.
         if constexpr (!FIRST) issue(b_fill);
         lane_offsets();
-        stamp();
         if constexpr (FIRST) open_kstep(b_cur);
+        stamp(std::integral_constant<int, 1>{});
         if constexpr (KS == 1) {
             // one k-step per stage: it prepares the NEXT stage's (landed: the barrier above), except an item's last
             if constexpr (LAST) kstep(first_tag, std::false_type{}, b_cur, 0, b_nxt, 0);
             else kstep(first_tag, std::true_type{}, b_cur, 0, b_nxt, 0);
             if constexpr (FIRST) issue(b_fill);
             if constexpr (!FIRST && !LAST) place_ahead();
-            stamp();
-            w2d_dma_wait();
-            stamp();
+            stamp(std::integral_constant<int, 2>{});
+            w2d_dma_wait<(ABL & 32768) != 0>();
+            stamp(std::integral_constant<int, 4>{});
             float* t1 = b_cur; b_cur = b_nxt; b_nxt = b_fill; b_fill = t1;
             return;
         }
+#ifndef AICG_EMULATED
+        // ABL 262144: the upper wave of a SIMD (waves w and w + 4 share one) at issue priority 1 -- the oldest-first arbitration lets the
+        // lower wave run ahead and wait ~1 900 cycles per stage at the barrier; with the priority the roles swap and the stage is as long
+        if constexpr ((ABL & 262144) != 0) { if (wave >= 4) __builtin_amdgcn_s_setprio(1); }
+#endif
         kstep(first_tag, std::true_type{}, b_cur, 0, b_cur, 1);
         if constexpr (FIRST) issue(b_fill);
         // (steady stages only: with more than three chunks per item that is where the cursor wraps; an item's first and last stages keep
         //  their register budgets -- behind the last stage's first k-step the placement's temporaries pushed accumulators through scratch)
         if constexpr (!FIRST && !LAST) place_ahead();
-        stamp();
+        stamp(std::integral_constant<int, 2>{});
         if constexpr (LAST) kstep(std::false_type{}, std::false_type{}, b_cur, 1, b_nxt, 0);
         else kstep(std::false_type{}, std::true_type{}, b_cur, 1, b_nxt, 0);
-        stamp();
-        w2d_dma_wait();
-        stamp();
+        stamp(std::integral_constant<int, 3>{});
+        w2d_dma_wait<(ABL & 32768) != 0>();
+        stamp(std::integral_constant<int, 4>{});
         float* t = b_cur; b_cur = b_nxt; b_nxt = b_fill; b_fill = t;
     };
     for (int k = 0; k < my_items; ++k) {
@@ -584,7 +599,15 @@ __global__ void __launch_bounds__(64 * NW, KS == 1 ? 2 : 1) conv_w2d_kernel(Conv
         // per (row block, register).  Lanes l15 and l15 ^ 1 trade halves (one DPP move each way): the even lane stores the upper row
         // of both blocks -- four consecutive columns, one 16-byte store --, the odd lane the lower row: 12 stores per lane and item
         // instead of 24, each wave instruction eight 128-byte runs.
-        if constexpr ((dbg & 16) != 0) continue;
+        if constexpr ((dbg & 16) != 0) {                 // (the accumulators stay live: the asm MFMAs of an unread result would be deleted)
+#ifndef AICG_EMULATED
+#pragma unroll
+            for (int pt = 0; pt < 16; ++pt)
+#pragma unroll
+                for (int rb = 0; rb < 3; ++rb) asm volatile("" :: "v"(acc[pt][rb]));
+#endif
+            continue;
+        }
         if constexpr (TIED) w2d_mfma_settle();
         w2d_fence();   // the epilogue's index arithmetic stays out of the last k-step (scheduled into it, it pushed accumulators into scratch memory)
         const int tw_i = tile % p.tiles_w, th_i = (tile / p.tiles_w) % p.tiles_h, n = tile / (p.tiles_w * p.tiles_h);
@@ -637,7 +660,6 @@ __global__ void __launch_bounds__(64 * NW, KS == 1 ? 2 : 1) conv_w2d_kernel(Conv
                 }
             }
         };
-        stamp();
         if (full) {
             if (p.act == AICG_ACT_NONE) body(std::integral_constant<int, 0>{}, std::true_type{});
             else if (p.act == AICG_ACT_RELU) body(std::integral_constant<int, 1>{}, std::true_type{});
@@ -647,12 +669,19 @@ __global__ void __launch_bounds__(64 * NW, KS == 1 ? 2 : 1) conv_w2d_kernel(Conv
             else if (p.act == AICG_ACT_RELU) body(std::integral_constant<int, 1>{}, std::false_type{});
             else body(std::integral_constant<int, 3>{}, std::false_type{});
         }
-        stamp();
+        stamp(std::integral_constant<int, 5>{});
     }
 #ifndef AICG_EMULATED
     if ((dbg & (64 | 256)) != 0 && blockIdx.x == 0 && tid == 0) {
         p.y[0] = (float)(clock64() - clk0);
-        p.y[1] = (dbg & 256) ? (float)tr_n : (float)(wall_clock64() - wall0);
+        p.y[1] = (float)(wall_clock64() - wall0);
+    }
+    if constexpr ((dbg & 256) != 0) {                // per wave of workgroup 0: y[16 + 8 wave + phase]; y[8] = its items
+        if (blockIdx.x == 0 && (tid & 63) == 0) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) p.y[16 + 8 * wave + k] = (float)tph[k];
+            if (tid == 0) p.y[8] = (float)my_items;
+        }
     }
 #endif
 }

@@ -1,10 +1,4 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r6n
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r6q
 export AICG_DEV=1
-timeout 600 python -m pytest tests/test_conv.py -q -m gpu -k winograd_2d 2>&1 | tail -2
-timeout 600 python -c "
-import aicovergen_amd._lib as L, sys
-L._DEFAULT = L._DEFAULT.replace('hip.so', 'hip_dev.so')
-import pytest
-sys.exit(pytest.main(['tests/test_conv.py', '-q', '-m', 'gpu', '-k', 'winograd_2d']))" 2>&1 | tail -2
-timeout 600 python tools/kbench_w2d_ab.py 12,4,2,14 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r6n/kbench_w2d_tied.txt
-timeout 900 python tools/kbench_w2d_ablate.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r6n/kbench_w2d_ablation_tied.txt
+KB_ONLY=256,262400 timeout 600 python tools/kbench_w2d_ablate.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r6q/kbench_w2d_phases_by_wave.txt
+timeout 600 python tools/kbench_w2d_ab.py 12,18,19 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r6q/kbench_w2d_prio.txt
