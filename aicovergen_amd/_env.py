@@ -2,6 +2,9 @@
 
 Supported in a user's process:
     AICG_PRECISION=bf16x3        opt-in split precision for the conv / TDF family (the f0 models stay fp32)
+    AICG_HALF=1                  opt-in fp16 matrix arithmetic where the caller ALSO passes is_half=True (src/main.py:196 does): HuBERT's and the
+                                 synthesizer's LDS-DMA staged layers take fp16 operands, fp32 activations / accumulation (ops.mark_half; the f0
+                                 models, SineGen, attention and MDX-Net stay fp32).  Without it .half() is a no-op and everything is fp32
     AICG_FORCE_COLLECTIVES=1     a one-rank process group runs every join through the real collectives (tests/test_rccl_one_rank.py)
 
 Everything else -- kernel-form selectors (AICG_WINOGRAD, AICG_WINOGRAD1D, AICG_W2D_*, AICG_GRU_*), schedule selectors (AICG_F0_SEGMENTS,

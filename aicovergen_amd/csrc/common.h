@@ -219,6 +219,41 @@ __device__ __forceinline__ mfma_f32x16 mfma_bf16_32x32x16(const float4& a, const
 #endif
 }
 
+// ---- opt-in fp16 matrix arithmetic (aicg_conv_desc.split == 2: the reference's is_half mode on the RVC half, src/rvc.py:103-104,137-138):
+// operands rounded to fp16 (round to nearest even, v_cvt_pk_f16_f32) in registers right in front of the MFMA, fp32 accumulation, fp32
+// activations in HBM.  Four fp16 (k = 4 half .. 4 half + 3 of an 8-row K group) packed in two dwords: element e in bits 16 (e & 1) of
+// word e >> 1.
+struct H4 { unsigned x, y; };
+__device__ __forceinline__ H4 pack_f16x4(float v0, float v1, float v2, float v3) {
+    H4 r;
+#ifdef AICG_EMULATED
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    typedef float f2_t __attribute__((ext_vector_type(2)));
+    const f2_t a = {v0, v1}, b = {v2, v3};
+    r.x = __builtin_bit_cast(unsigned, __builtin_convertvector(a, h2_t));
+    r.y = __builtin_bit_cast(unsigned, __builtin_convertvector(b, h2_t));
+#else
+    // (inline asm: through __builtin_convertvector hipcc kept the fragment quads the values come from in scratch memory.  The hazard
+    //  recogniser does not look inside: a VALU result needs two wait states before an MFMA reads it, hence the s_nop)
+    asm("v_cvt_pk_f16_f32 %0, %2, %3\n\tv_cvt_pk_f16_f32 %1, %4, %5\n\ts_nop 1" : "=&v"(r.x), "=&v"(r.y) : "v"(v0), "v"(v1), "v"(v2), "v"(v3));
+#endif
+    return r;
+}
+__device__ __forceinline__ mfma_f32x16 mfma_f16_32x32x8(const H4& a, const H4& b, mfma_f32x16 c) {
+#ifdef AICG_EMULATED
+    const unsigned aw[2] = {a.x, a.y}, bw[2] = {b.x, b.y};
+    for (int e = 0; e < 4; ++e) {   // four two-row contractions of the fp32 MFMA model: lane half h supplies k = 4 h + e
+        const unsigned short ab = (unsigned short)(aw[e >> 1] >> (16 * (e & 1))), bb = (unsigned short)(bw[e >> 1] >> (16 * (e & 1)));
+        const float av = (float)__builtin_bit_cast(_Float16, ab), bv = (float)__builtin_bit_cast(_Float16, bb);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, c, 0, 0, 0);
+    }
+    return c;
+#else
+    typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+    return __builtin_amdgcn_mfma_f32_32x32x8f16(__builtin_bit_cast(f16x4_t, a), __builtin_bit_cast(f16x4_t, b), c, 0, 0, 0);
+#endif
+}
+
 // value of the lane whose id differs in bit 0 / bit 1 (exchange inside a quad of lanes): one DPP move on the hardware
 __device__ __forceinline__ float quad_xor1(float v) {
 #ifdef AICG_EMULATED

@@ -150,7 +150,8 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
     p.Cin_pad = idiv_up(p.Cin_g, 32) * 32;
     p.w_group_stride = (long)p.taps * p.Cin_pad * p.Mpad;
     p.w3 = d->packed_v3 ? w_packed + (long)p.groups * p.w_group_stride : nullptr;
-    p.wsplit = d->packed_v3 && d->split ? w_packed + 2L * p.groups * p.w_group_stride : nullptr;
+    p.wsplit = d->packed_v3 && d->split == 1 ? w_packed + 2L * p.groups * p.w_group_stride : nullptr;
+    p.f16 = d->split == 2;
 
     if (d->wino == 8) {
         // one-dimensional Winograd F(2, 3) of a k = 3 / 7 / 11, dilation-1 layer (conv_g1w.h): w_packed is the image pair of the
@@ -176,7 +177,7 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
         else if (p.dw == 1 && (d->gemm_tile == 6 || d->gemm_tile == 7)) rc = run_g1w_32x512_pers(p, st8);
         else
 #endif
-            rc = run_g1w_32x512(p, st8);
+            rc = p.f16 ? run_g1w_32x512_h(p, st8) : run_g1w_32x512(p, st8);
         if (rc == 1) return fail(AICG_E_SHAPE, "aicg_conv_forward: wino 8 layer does not fit the kernel's LDS budget");
         return rc;
     }
@@ -290,7 +291,14 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
             auto wgs = [&](int bm) { return (long)p.N * idiv_up(M, bm) * ldiv_up(HW, 256); };
             hipStream_t gst = (hipStream_t)stream;
             int rc = 1;
-            if (g1 == 2) rc = run_g1_128x256(p, gst);
+            if (p.f16 && !p.shuffle) {
+                // fp16 operands: a quarter of the MFMA time per tile -- the 64-row tile (three workgroups per CU) unless 128 rows divide
+                // the layer better
+                const long t64 = wgs(64), t128 = wgs(128);
+                if (g1 == 3 || (g1 != 2 && ldiv_up(t64, 768) * 64 < ldiv_up(t128, 512) * 128)) rc = run_g1_64x256_h(p, gst);
+                else rc = run_g1_128x256_h(p, gst);
+            }
+            else if (g1 == 2) rc = run_g1_128x256(p, gst);
             else if (g1 == 3) rc = run_g1_64x256(p, gst);
             else if (g1 == 4) rc = run_g1_192x256(p, gst);
 #ifdef AICG_DEV_SWITCHES

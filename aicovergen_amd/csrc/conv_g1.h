@@ -146,7 +146,11 @@ __device__ __forceinline__ void g1_epilogue(const ConvArgs& p, f32x16 (&acc)[TM]
 // SPREAD: the DMA pieces of a stage go out one at a time between the MFMAs (see mma_group) instead of as one burst behind the barrier.
 // PRE: a leaky-ReLU input activation (0 <= slope <= 1: the vocoder's up-sampling GEMMs, models.py:503), applied to the B fragments in
 // registers right in front of the k-step that consumes them -- 8 VALU operations under the previous k-step's 4 TM MFMAs.
-template <int TM, int WM, int WN, bool SHUF, int WPS, bool SPREAD, bool PRE>
+// F16 (aicg_conv_desc.split == 2, the reference's is_half mode): the same staging and the same fp32 images; a k-group's fragments -- an A
+// quad = a row's four k-steps, the B quads of four k-steps = 4 x 4 (k-step, position) values -- are rounded to fp16 in registers and
+// contracted by ONE v_mfma_f32_32x32x8_f16 per (row tile, position tile) where the fp32 path issues four 32 x 32 x 2 MFMAs: lane half h
+// supplies k = 4 h + e <-> channel 2 e + h of the group on both operands.  fp32 accumulation and epilogue.
+template <int TM, int WM, int WN, bool SHUF, int WPS, bool SPREAD, bool PRE, bool F16 = false>
 __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1_kernel(ConvArgs p) {
     static_assert(WM * WN == 4, "four waves");
     constexpr int BM = 32 * TM * WM, BN = 128 * WN;
@@ -232,6 +236,34 @@ __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1_kernel(C
     auto mma_group = [&](const float4 (&a)[TM], const float4 (&b)[4], auto dma_tag, bool more, float* fill) __attribute__((always_inline)) {
         constexpr bool DMA = decltype(dma_tag)::value;
         constexpr int NBLK = 4 * TM;
+        if constexpr (F16) {
+            // (scalars, not a copied float4 array: hipcc put that one in scratch memory)
+            auto pre = [&](float v) __attribute__((always_inline)) { return PRE ? fmaxf(v, v * pre_slope) : v; };
+            const H4 bh0 = pack_f16x4(pre(b[0].x), pre(b[1].x), pre(b[2].x), pre(b[3].x));
+            const H4 bh1 = pack_f16x4(pre(b[0].y), pre(b[1].y), pre(b[2].y), pre(b[3].y));
+            const H4 bh2 = pack_f16x4(pre(b[0].z), pre(b[1].z), pre(b[2].z), pre(b[3].z));
+            const H4 bh3 = pack_f16x4(pre(b[0].w), pre(b[1].w), pre(b[2].w), pre(b[3].w));
+            auto piece_behind = [&](int blk) __attribute__((always_inline)) {
+                if constexpr (DMA) {
+                    w2d_fence();
+                    if (more) {
+#pragma unroll
+                        for (int e = 0; e < PW; ++e)
+                            if (e * NBLK / PW == blk) issue_piece(e, fill);
+                    }
+                    w2d_fence();
+                }
+            };
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const H4 ah = pack_f16x4(a[i].x, a[i].y, a[i].z, a[i].w);
+                acc[i][0] = mfma_f16_32x32x8(ah, bh0, acc[i][0]); piece_behind(i * 4 + 0);
+                acc[i][1] = mfma_f16_32x32x8(ah, bh1, acc[i][1]); piece_behind(i * 4 + 1);
+                acc[i][2] = mfma_f16_32x32x8(ah, bh2, acc[i][2]); piece_behind(i * 4 + 2);
+                acc[i][3] = mfma_f16_32x32x8(ah, bh3, acc[i][3]); piece_behind(i * 4 + 3);
+            }
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -320,7 +352,7 @@ inline bool conv_g1_applicable(const ConvArgs& p, int pad_h_end, int pad_w_end) 
     return true;
 }
 
-template <int TM, int WM, int WN, int WPS, bool SPREAD = true>
+template <int TM, int WM, int WN, int WPS, bool SPREAD = true, bool F16 = false>
 static int launch_conv_g1(ConvArgs& p, hipStream_t stream) {
     constexpr int BM = 32 * TM * WM, BN = 128 * WN;
     const long HW = (long)p.H * p.W;
@@ -330,8 +362,9 @@ static int launch_conv_g1(ConvArgs& p, hipStream_t stream) {
     if (nwg > 2147483647L) return fail(AICG_E_SHAPE, "conv: too many output tiles");
     const size_t lds = (size_t)kG1Bufs * g1_stage_floats(BM, BN) * sizeof(float);
     if (lds > 160 * 1024) return 1;
+    if (F16 && p.shuffle) return 1;                  // (the pixel-shuffle layers are MDX-Net's: no is_half mode there)
     auto kern = p.shuffle ? conv_g1_kernel<TM, WM, WN, true, WPS, SPREAD, false>
-                          : p.pre_act != AICG_ACT_NONE ? conv_g1_kernel<TM, WM, WN, false, WPS, SPREAD, true> : conv_g1_kernel<TM, WM, WN, false, WPS, SPREAD, false>;
+                          : p.pre_act != AICG_ACT_NONE ? conv_g1_kernel<TM, WM, WN, false, WPS, SPREAD, true, F16> : conv_g1_kernel<TM, WM, WN, false, WPS, SPREAD, false, F16>;
     allow_dynamic_lds((const void*)kern, lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, stream, p);
     return check_launch("conv_g1_kernel");
@@ -341,6 +374,8 @@ static int launch_conv_g1(ConvArgs& p, hipStream_t stream) {
 int run_g1_128x256(ConvArgs& p, hipStream_t st);    // wave 64 x 128 (2 x 4 tiles), two workgroups per CU
 int run_g1_64x256(ConvArgs& p, hipStream_t st);     // wave 32 x 128, up to three per CU
 int run_g1_192x256(ConvArgs& p, hipStream_t st);    // wave 96 x 128, one per CU
+int run_g1_128x256_h(ConvArgs& p, hipStream_t st);  // the same tiles on the fp16 matrix pipe (aicg_conv_desc.split == 2; conv_g1_2.hip)
+int run_g1_64x256_h(ConvArgs& p, hipStream_t st);
 #ifdef AICG_DEV_SWITCHES
 int run_g1_256x256(ConvArgs& p, hipStream_t st);    // wave 128 x 128 (tools/kbench_g1.py)
 int run_g1_128x512(ConvArgs& p, hipStream_t st);    // wave 128 x 128, four waves side by side

@@ -75,10 +75,15 @@ __device__ __forceinline__ float g1w_w(const float4 (&q)[5]) {        // W[I] ou
 // PERS (d = 1): a workgroup WALKS tiles (blockIdx.x, + gridDim.x, ...): the unit pipeline runs on into the next tile -- its first window
 // and its first two units' weights are issued under the last units of the running tile -- so that only the first tile of a workgroup
 // waits for HBM in its prologue (a tile of a k = 3 layer is 50 us of work behind ~3 us of first-window latency).
-template <int K, int D, int WM, int WN, int WPS, bool PRE, int SCH = 0, bool PERS = false>
+// F16 (aicg_conv_desc.split == 2, the reference's is_half mode): same staging, same fp32 images, same transform B^T d in fp32; the
+// operands of a unit's four k-steps are rounded to fp16 in registers -- per slot the A quad, per (tile, slot) the four k-steps' V -- and a
+// unit is 2 x slots v_mfma_f32_32x32x8_f16 instead of 8 x slots fp32 MFMAs.  The next unit's operands are read, transformed and packed
+// behind the running unit's MFMAs (issued, not waited for: their results are next needed by the next unit's MFMAs).
+template <int K, int D, int WM, int WN, int WPS, bool PRE, int SCH = 0, bool PERS = false, bool F16 = false>
 __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1w_kernel(ConvArgs p) {
     using PL = G1wPlan<K, D>;
     static_assert(WM * WN == 4, "four waves");
+    static_assert(!F16 || (SCH == 0 && !PERS), "the fp16 form has one schedule");
     static_assert(!PERS || D == 1, "the dilated epilogue's LDS tiles overlay the pipeline's buffers");
     constexpr int BM = 32 * WM, BN = PL::SPAN * WN;
     constexpr int RQ = g1w_row_quads(BN, K, D);
@@ -269,11 +274,11 @@ __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1w_kernel(
         load_a(std::integral_constant<int, 0>{}, a_cur, af);
         prep(std::integral_constant<int, 0>{}, 0, bbuf + wpar * BSTAGE, 0, Vc);
     };
-    open_tile();
+    if constexpr (!F16) open_tile();
     // One unit of the walk; V (unit inside the stage) at compile time.  MODE 0: a unit with a successor in the same tile (the next unit's
     // operands are prefetched into registers under this one's last k-steps); 1: a tile's last unit with another tile behind it (PERS: the
     // barrier and the DMA issue go on, the register prefetch does not -- the epilogue in between needs the registers); 2: the walk's last.
-    auto run_unit = [&](auto v_tag, auto mode_tag, int cs) __attribute__((always_inline)) {
+    auto run_unit_f = [&](auto v_tag, auto mode_tag, int cs) __attribute__((always_inline)) {
         constexpr int V = decltype(v_tag)::value;
         constexpr int MODE = decltype(mode_tag)::value;
         constexpr bool PREF = MODE == 0, SYNC = MODE != 2;
@@ -342,10 +347,70 @@ __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1w_kernel(
         float* t = a_cur; a_cur = a_nxt; a_nxt = a_fill; a_fill = t;
         if constexpr (V + 1 == PL::NU) wpar ^= 1;
     };
+    // ---- F16: a unit's operands packed in registers
+    H4 ah[4], Vh[2][4];                                   // running unit: A per slot, V per (tile, slot): the four k-steps' values
+    auto pack_unit = [&](auto g_tag, const float* abuf, const float* wsrc, int rb_) __attribute__((always_inline)) {
+        constexpr int NS = PL::slots_of(decltype(g_tag)::value);
+        float4 a4[4];
+        load_a(g_tag, abuf, a4);
+        float Vf[4][2][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) prep(g_tag, s, wsrc, rb_, Vf[s]);
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) ah[sl] = pack_f16x4(a4[sl].x, a4[sl].y, a4[sl].z, a4[sl].w);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) Vh[j][sl] = pack_f16x4(Vf[0][j][sl], Vf[1][j][sl], Vf[2][j][sl], Vf[3][j][sl]);
+    };
+    auto run_unit_h = [&](auto v_tag, auto mode_tag, int cs) __attribute__((always_inline)) {
+        constexpr int V = decltype(v_tag)::value;
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr bool PREF = MODE == 0, SYNC = MODE != 2;
+        constexpr int G = K == 3 ? 0 : V;
+        constexpr int VN = (V + 1) % PL::NU, GN = K == 3 ? 0 : VN;
+        constexpr int NS = PL::slots_of(G);
+        using GNT = std::integral_constant<int, GN>;
+        const int rbn = K == 3 ? 8 * VN : 0;
+        const float* wnxt = bbuf + (V + 1 == PL::NU ? wpar ^ 1 : wpar) * BSTAGE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if constexpr (NS == 4) {
+                M[0][j] = mfma_f16_32x32x8(ah[0], Vh[j][0], M[0][j]); M[1][j] = mfma_f16_32x32x8(ah[1], Vh[j][1], M[1][j]);
+                M[2][j] = mfma_f16_32x32x8(ah[2], Vh[j][2], M[2][j]); M[3][j] = mfma_f16_32x32x8(ah[3], Vh[j][3], M[3][j]);
+            } else if constexpr (NS == 3) {
+                M[0][j] = mfma_f16_32x32x8(ah[0], Vh[j][0], M[0][j]); M[1][j] = mfma_f16_32x32x8(ah[1], Vh[j][1], M[1][j]);
+                M[3][j] = mfma_f16_32x32x8(ah[2], Vh[j][2], M[3][j]);
+            } else {
+                M[0][j] = mfma_f16_32x32x8(ah[0], Vh[j][0], M[0][j]); M[3][j] = mfma_f16_32x32x8(ah[1], Vh[j][1], M[3][j]);
+            }
+        }
+        w2d_fence();
+        if constexpr (SYNC) {
+            g1_wait_pieces<0>();
+            lds_barrier();
+            if constexpr (V == 0) {
+                if (cs + 1 < nst) issue_b(boff, ximg, cs + 1, bbuf + (wpar ^ 1) * BSTAGE);
+            }
+            {
+                constexpr int V2 = (V + 2) % PL::NU;
+                const int cs2 = cs + (V + 2) / PL::NU;
+                if (cs2 < nst) issue_unit(aoff, cs2, V2, a_fill);
+            }
+            if constexpr (PREF) pack_unit(GNT{}, a_nxt, wnxt, rbn);
+        }
+        w2d_fence();
+        float* t = a_cur; a_cur = a_nxt; a_nxt = a_fill; a_fill = t;
+        if constexpr (V + 1 == PL::NU) wpar ^= 1;
+    };
     using M0 = std::integral_constant<int, 0>;
     // the units of one tile; END = the mode of its last unit
     auto run_tile = [&](auto end_tag) __attribute__((always_inline)) {
         using END = decltype(end_tag);
+        auto run_unit = [&](auto v_tag, auto mode_tag, int cs_) __attribute__((always_inline)) {
+            if constexpr (F16) run_unit_h(v_tag, mode_tag, cs_);
+            else run_unit_f(v_tag, mode_tag, cs_);
+        };
         for (int cs = 0; cs + 1 < nst; ++cs) {
             run_unit(std::integral_constant<int, 0>{}, M0{}, cs);
             if constexpr (PL::NU > 1) run_unit(std::integral_constant<int, 1>{}, M0{}, cs);
@@ -424,6 +489,7 @@ __global__ void __launch_bounds__(256) AICG_WAVES_PER_SIMD(WPS) conv_g1w_kernel(
     }
     };
     if constexpr (!PERS) {
+        if constexpr (F16) pack_unit(std::integral_constant<int, 0>{}, a_cur, bbuf + wpar * BSTAGE, 0);
         run_tile(std::integral_constant<int, 2>{});
         epilogue();
     } else {
@@ -482,7 +548,7 @@ inline bool conv_g1w_applicable(const ConvArgs& p, int pad_w_end) {
     return true;
 }
 
-template <int K, int D, int WM, int WN, int WPS, int SCH, bool PERS = false>
+template <int K, int D, int WM, int WN, int WPS, int SCH, bool PERS = false, bool F16 = false>
 static int launch_conv_g1w_kd(ConvArgs& p, hipStream_t stream) {
     using PL = G1wPlan<K, D>;
     constexpr int BM = 32 * WM, BN = PL::SPAN * WN;
@@ -493,7 +559,7 @@ static int launch_conv_g1w_kd(ConvArgs& p, hipStream_t stream) {
     size_t lds = (size_t)(3 * 4 * 2 * BM * 4 + 2 * ((PL::CS * g1w_row_quads(BN, K, D) + 63) / 64) * 256) * sizeof(float);
     if (D > 1 && lds < (size_t)4 * 32 * (PL::SPAN + 4) * sizeof(float)) lds = (size_t)4 * 32 * (PL::SPAN + 4) * sizeof(float);   // the epilogue's tiles
     if (lds > 160 * 1024) return 1;
-    auto kern = p.pre_act != AICG_ACT_NONE ? conv_g1w_kernel<K, D, WM, WN, WPS, true, SCH, PERS> : conv_g1w_kernel<K, D, WM, WN, WPS, false, SCH, PERS>;
+    auto kern = p.pre_act != AICG_ACT_NONE ? conv_g1w_kernel<K, D, WM, WN, WPS, true, SCH, PERS, F16> : conv_g1w_kernel<K, D, WM, WN, WPS, false, SCH, PERS, F16>;
     allow_dynamic_lds((const void*)kern, lds);
     long grid = nwg;
     const long slots = p.dbg > 0 ? p.dbg : 2 * 256;      // two workgroups per CU, each walking tiles blockIdx.x, + grid, ... (p.dbg: tests)
@@ -502,23 +568,23 @@ static int launch_conv_g1w_kd(ConvArgs& p, hipStream_t stream) {
     return check_launch("conv_g1w_kernel");
 }
 
-template <int WM, int WN, int WPS, int SCH = 0, bool DIL = true, bool PERS = false>
+template <int WM, int WN, int WPS, int SCH = 0, bool DIL = true, bool PERS = false, bool F16 = false>
 static int launch_conv_g1w(ConvArgs& p, hipStream_t stream) {
     if (p.dw == 1) {
-        if (p.KW == 3) return launch_conv_g1w_kd<3, 1, WM, WN, WPS, SCH, PERS>(p, stream);
-        if (p.KW == 5) return launch_conv_g1w_kd<5, 1, WM, WN, WPS, SCH, PERS>(p, stream);
-        if (p.KW == 7) return launch_conv_g1w_kd<7, 1, WM, WN, WPS, SCH, PERS>(p, stream);
-        return launch_conv_g1w_kd<11, 1, WM, WN, WPS, SCH, PERS>(p, stream);
+        if (p.KW == 3) return launch_conv_g1w_kd<3, 1, WM, WN, WPS, SCH, PERS, F16>(p, stream);
+        if (p.KW == 5) return launch_conv_g1w_kd<5, 1, WM, WN, WPS, SCH, PERS, F16>(p, stream);
+        if (p.KW == 7) return launch_conv_g1w_kd<7, 1, WM, WN, WPS, SCH, PERS, F16>(p, stream);
+        return launch_conv_g1w_kd<11, 1, WM, WN, WPS, SCH, PERS, F16>(p, stream);
     }
     if constexpr (DIL) {
         if (p.dw == 3) {
-            if (p.KW == 3) return launch_conv_g1w_kd<3, 3, WM, WN, WPS, SCH>(p, stream);
-            if (p.KW == 7) return launch_conv_g1w_kd<7, 3, WM, WN, WPS, SCH>(p, stream);
-            return launch_conv_g1w_kd<11, 3, WM, WN, WPS, SCH>(p, stream);
+            if (p.KW == 3) return launch_conv_g1w_kd<3, 3, WM, WN, WPS, SCH, false, F16>(p, stream);
+            if (p.KW == 7) return launch_conv_g1w_kd<7, 3, WM, WN, WPS, SCH, false, F16>(p, stream);
+            return launch_conv_g1w_kd<11, 3, WM, WN, WPS, SCH, false, F16>(p, stream);
         }
-        if (p.KW == 3) return launch_conv_g1w_kd<3, 5, WM, WN, WPS, SCH>(p, stream);
-        if (p.KW == 7) return launch_conv_g1w_kd<7, 5, WM, WN, WPS, SCH>(p, stream);
-        return launch_conv_g1w_kd<11, 5, WM, WN, WPS, SCH>(p, stream);
+        if (p.KW == 3) return launch_conv_g1w_kd<3, 5, WM, WN, WPS, SCH, false, F16>(p, stream);
+        if (p.KW == 7) return launch_conv_g1w_kd<7, 5, WM, WN, WPS, SCH, false, F16>(p, stream);
+        return launch_conv_g1w_kd<11, 5, WM, WN, WPS, SCH, false, F16>(p, stream);
     }
     return 1;
 }
@@ -526,6 +592,7 @@ static int launch_conv_g1w(ConvArgs& p, hipStream_t stream) {
 // instantiation unit conv_g1w_1.hip
 int run_g1w_64x256(ConvArgs& p, hipStream_t st);    // 2 x 2 waves of 32 rows x 128 outputs
 int run_g1w_32x512(ConvArgs& p, hipStream_t st);    // 1 x 4 waves: all four share the tile's 32 rows
+int run_g1w_32x512_h(ConvArgs& p, hipStream_t st);  // ... on the fp16 matrix pipe (aicg_conv_desc.split == 2; conv_g1w_4.hip)
 int run_g1w_32x512_sched(ConvArgs& p, hipStream_t st);   // ... with the explicit MFMA / VALU interleave (SCH)
 int run_g1w_32x512_pers(ConvArgs& p, hipStream_t st);    // ... as a persistent tile walk (d = 1)
 

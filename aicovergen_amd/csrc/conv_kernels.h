@@ -69,6 +69,7 @@ struct ConvArgs {
     // tile's lifetime); half a tile out of phase, one workgroup's prologue / epilogue runs under the other's MFMAs.
     int stagger, stagger_first;
     int wide_ok;   // y (and res) rows are 16-byte aligned and TW % 4 == 0: interior tiles may use the float4 epilogue
+    int f16;  // aicg_conv_desc.split == 2: fp16 operands on the matrix pipe where the layer's kernel has that form (conv_g1.h, conv_g1w.h)
     int dbg;  // AICG_CONV_ABLATE bits (profiling only): 1 no global loads, 2 no LDS commit, 4 no barriers, 8 no MFMA loop, 16 no epilogue
 };
 

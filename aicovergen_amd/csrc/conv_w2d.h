@@ -409,6 +409,14 @@ __global__ void __launch_bounds__(64 * NW, KS == 1 ? 2 : 1) conv_w2d_kernel(Conv
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q) V[4 * i + q] = N[i][q];
+#ifndef AICG_EMULATED
+        // TIED: the MFMAs that read V are inline asm, which the hazard recogniser does not see -- a VALU result needs two wait states
+        // before an MFMA reads it (hipcc puts an s_nop 1 there for the builtin).  One s_nop per k-step with all sixteen V as operands:
+        // every V is written in front of it, every MFMA of the next k-step reads the values behind it.
+        if constexpr (TIED)
+            asm volatile("s_nop 1" : "+v"(V[0]), "+v"(V[1]), "+v"(V[2]), "+v"(V[3]), "+v"(V[4]), "+v"(V[5]), "+v"(V[6]), "+v"(V[7]), "+v"(V[8]),
+                         "+v"(V[9]), "+v"(V[10]), "+v"(V[11]), "+v"(V[12]), "+v"(V[13]), "+v"(V[14]), "+v"(V[15]));
+#endif
     };
     auto fetch_q = [&](const float* stage, int s, int pg, int rb) __attribute__((always_inline)) {      // AQ: row block rb's fragments of point group pg of k-step s
         if constexpr ((dbg & 2) != 0) return;

@@ -65,9 +65,17 @@ class HubertModel:
         return self
 
     def half(self):
-        return self  # fp32 kernels (>= the reference's fp16 GPU path, src/rvc.py:103-104)
+        # fp32 kernels by default (>= the reference's fp16 GPU path, src/rvc.py:103-104); AICG_HALF=1: fp16 operands on the matrix pipe for
+        # the layers on the LDS-DMA staged kernels (ops.mark_half)
+        self._half = ops.half_requested()
+        if self._p is not None:
+            ops.mark_half(self._p, self._half)
+        return self
 
     def float(self):
+        self._half = False
+        if self._p is not None:
+            ops.mark_half(self._p, False)
         return self
 
     def eval(self):
@@ -122,6 +130,8 @@ class HubertModel:
         P["layers"] = layers
         if "final_proj.weight" in sd:
             P["final_proj"] = ops.PackedConv(sd["final_proj.weight"], sd["final_proj.bias"], device=dev)
+        if getattr(self, "_half", False):
+            ops.mark_half(P, True)
         self._p = P
         return P
 

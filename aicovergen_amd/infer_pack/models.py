@@ -78,10 +78,17 @@ class _SynthesizerBase:
         return self
 
     def half(self):
-        # The reference runs fp16 on GPU (src/rvc.py:137-138); these kernels compute in fp32 (>= that precision).
+        # The reference runs fp16 on GPU (src/rvc.py:137-138).  Default: fp32 kernels (>= that precision); with AICG_HALF=1 the layers on
+        # the LDS-DMA staged kernels take fp16 operands on the matrix pipe (ops.mark_half; fp32 activations and accumulation)
+        self._half = ops.half_requested()
+        if self._p is not None:
+            ops.mark_half(self._p, self._half)
         return self
 
     def float(self):
+        self._half = False
+        if self._p is not None:
+            ops.mark_half(self._p, False)
         return self
 
     def remove_weight_norm(self):
@@ -198,6 +205,8 @@ class _SynthesizerBase:
         if self.use_f0:
             P["lin_w"] = float(sd["dec.m_source.l_linear.weight"].reshape(-1)[0])
             P["lin_b"] = float(sd["dec.m_source.l_linear.bias"].reshape(-1)[0])
+        if getattr(self, "_half", False):
+            ops.mark_half(P, True)
         self._p = P
         return P
 

@@ -159,6 +159,29 @@ def conv_bkc(taps):
 split_precision = os.environ.get("AICG_PRECISION", "fp32").lower() in ("bf16x3", "split")
 
 
+# Opt-in fp16 matrix arithmetic for the RVC half (AICG_HALF=1 AND the caller's is_half=True, i.e. what src/main.py:196 asks for and the
+# reference runs in fp16 on a GPU, src/rvc.py:103-104,137-138): HubertModel.half() / Synthesizer.half() mark their layers (mark_half), and a
+# marked layer that takes one of the LDS-DMA staged kernels (csrc/conv_g1.h, csrc/conv_g1w.h) rounds its operands to fp16 in registers in
+# front of the MFMA -- fp32 activations in HBM, fp32 accumulation, fp32 epilogue.  The f0 models, SineGen and every layer on another
+# kernel stay fp32.  Default (and the headline bench): off -- .half() is then the no-op it was.
+def half_requested():
+    return os.environ.get("AICG_HALF", "0") == "1"
+
+
+def mark_half(tree, on=True):
+    """Set / clear the fp16-operand flag on every PackedConv reachable from `tree` (dicts, lists, tuples, PackedConvTranspose)."""
+    if isinstance(tree, PackedConv):
+        tree.f16 = bool(on) and not tree.fp32_only and not tree.split
+    elif isinstance(tree, PackedConvTranspose):
+        mark_half(tree.gemm, on)
+    elif isinstance(tree, dict):
+        for v in tree.values():
+            mark_half(v, on)
+    elif isinstance(tree, (list, tuple)):
+        for v in tree:
+            mark_half(v, on)
+
+
 _fp32_depth = 0
 
 
@@ -313,6 +336,8 @@ class PackedConv:
         self.stride, self.padding, self.dilation = stride, padding, dilation
         device = weight.device if device is None else device
         self.split = bool(split_precision)
+        self.fp32_only = _fp32_depth > 0                    # packed inside fp32_layers(): never marked for fp16 operands
+        self.f16 = False                                    # mark_half()
         self.w = pack_conv_weight(weight.to(device), groups, self.split)
         self.bias = None if bias is None else bias.detach().to(device=device, dtype=torch.float32).contiguous()
         self.w_wino = self.w_wino2 = self.w_wino1 = None
@@ -448,7 +473,7 @@ def conv(x, pc, res=None, out=None, pre_act=ACT_NONE, pre_slope=0.0, act=ACT_NON
     d.pad_h_end, d.pad_w_end = (-1, -1) if pc.padding_end is None else pc.padding_end
     d.shuffle, d.res_mul = int(shuffle), 1 if res_mul else 0
     d.packed_v3 = 1
-    d.split = 1 if getattr(pc, "split", False) else 0
+    d.split = 1 if getattr(pc, "split", False) else 2 if getattr(pc, "f16", False) else 0
     # Winograd form: plain 3 x 3 layer, bias + none / ReLU epilogue, an even row length and enough output to fill the chip
     wino = (getattr(pc, "w_wino", None) is not None and not is1d and res is None and not accumulate and pre_act == ACT_NONE
             and out_scale == 1.0 and act in (ACT_NONE, ACT_RELU) and not shuffle and out_len is None and wo % 2 == 0

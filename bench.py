@@ -40,7 +40,7 @@ MFMA_PEAK = PEAK_F32_MFMA  # of the arithmetic in use: --precision bf16x3 spends
 PEAK_HBM = 8000.0       # GB/s spec (6290 measured float4 copy)
 
 
-def build_models(device, config, n_mdx, tiny=False, preset="fp16"):
+def build_models(device, config, n_mdx, tiny=False, preset="fp16", half=False):
     """`tiny` (tests/test_bench_launch.py only, never on a GPU box): the miniature networks of the CPU suite, so that the launch /
     sharding / reporting logic of this file can be exercised end to end on the kernel emulator."""
     from aicovergen_amd.hubert import HubertModel
@@ -83,6 +83,8 @@ def build_models(device, config, n_mdx, tiny=False, preset="fp16"):
     del net_g.enc_q
     net_g.load_state_dict(weights.synth_state_dict(weights.SYNTH_CFG_40K_V2, 1236), strict=False)
     net_g.eval().to(device)
+    if half:   # --precision f16 (AICG_HALF=1 is set): what load_hubert / get_vc do when is_half is passed (src/rvc.py:103-104,137-138)
+        hub, net_g = hub.half(), net_g.half()
     return mdxs, vc, hub, net_g
 
 
@@ -233,9 +235,12 @@ def main():
                          "selects, the headline), fp32 = 1,6,38,41.  Geometry only: the arithmetic is fp32 either way")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-step", action="store_true", help="skip the extra instrumented step behind the timed region")
-    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default=None,
+    ap.add_argument("--precision", choices=["fp32", "bf16x3", "f16"], default=None,
                     help="arithmetic of the conv / TDF GEMM family: fp32 MFMA (default, the headline) or the opt-in split precision "
-                         "(bf16 hi + lo operands, 3 bf16 MFMAs per product, fp32 accumulation); default: $AICG_PRECISION or fp32")
+                         "(bf16 hi + lo operands, 3 bf16 MFMAs per product, fp32 accumulation); f16: the reference's is_half mode on "
+                         "the RVC half -- HuBERT's and the synthesizer's LDS-DMA staged layers take fp16 operands on the matrix pipe (AICG_HALF=1 + "
+                         ".half(); fp32 activations and accumulation; MDX-Net, f0, attention stay fp32) -- a SEPARATE line, never the headline; "
+                         "default: $AICG_PRECISION or fp32")
     ap.add_argument("--track-seconds", type=float, default=None)
     ap.add_argument("--dump", type=str, default=None, help="write the last step's outputs (npz) for cross-checking runs")
     ap.add_argument("--conv-shapes", type=str, default=None, help="write the instrumented step's per-layer-shape conv table (JSON)")
@@ -291,6 +296,9 @@ def main():
     global MFMA_PEAK
     if args.precision is not None:
         ops.split_precision = args.precision == "bf16x3"
+    half_mode = args.precision == "f16"
+    if half_mode:
+        os.environ["AICG_HALF"] = "1"
     split_mode = bool(ops.split_precision)
     MFMA_PEAK = PEAK_BF16_MFMA / 3.0 if split_mode else PEAK_F32_MFMA
     strong = args.config == "C5"
@@ -299,7 +307,7 @@ def main():
     else:
         seconds = (args.track_seconds or TRACK_S) * world   # weak scaling: 240 s per GPU
     with contextlib.redirect_stdout(sys.stderr):      # the synthesizer constructors print like the reference's do
-        mdxs, vc, hub, net_g = build_models(device, args.config, args.mdx_models, tiny=emu, preset=args.preset)
+        mdxs, vc, hub, net_g = build_models(device, args.config, args.mdx_models, tiny=emu, preset=args.preset, half=half_mode)
     wave44 = song_like(seconds, 44100, 1234)
     wave44 = wave44 / max(np.max(wave44), abs(np.min(wave44)))
     wave44_dev = torch.from_numpy(wave44).to(device)     # inputs resident in HBM before the timed region
@@ -386,7 +394,8 @@ def main():
             "metric": "real-time factor (audio-sec/wall-sec) for MDX+RVC on 4-min 44.1 kHz track",
             "value": seconds * args.steps / dt, "unit": "x real-time", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong" if strong else "weak",
-            "vs_baseline": None, "dtype": "bf16x3 (bf16 hi+lo operands, f32 accumulate; f0 / kNN f32)" if split_mode else "f32",
+            "vs_baseline": None, "dtype": "bf16x3 (bf16 hi+lo operands, f32 accumulate; f0 / kNN f32)" if split_mode
+            else "f16 operands on the matrix pipe for HuBERT's and the synthesizer's conv_g1 / conv_g1w layers (f32 activations, f32 accumulate); MDX-Net, f0, attention, everything else f32" if half_mode else "f32",
             "data": "synthetic",
             "config": {"workload": workload, "config_id": args.config, "mdx_models": args.mdx_models,
                        "audio_seconds_total": seconds,

@@ -120,7 +120,12 @@ typedef struct aicg_conv_desc {
                                      bf16(w) round-to-nearest-even, lo = bf16(w - hi)); layers with >= 16 input channels per
                                      group and more than 16 output channels are then computed as hi*hi + hi*lo + lo*hi on the
                                      bf16 matrix pipe with fp32 accumulation (csrc/conv_ws3s.h: ~1e-5 relative to the fp32
-                                     kernels); the other layers run the fp32 kernels unchanged */
+                                     kernels); the other layers run the fp32 kernels unchanged.
+                                     2 (no third image): fp16 operands -- the reference's is_half mode (src/rvc.py:103-104,137-138)
+                                     -- where the layer takes csrc/conv_g1.h (1 x 1 GEMM) or csrc/conv_g1w.h (wino == 8): both
+                                     operands rounded to fp16 (nearest even) in registers in front of v_mfma_f32_32x32x8_f16, fp32
+                                     activations, accumulation and epilogue (~1e-3 relative to the fp32 kernels); layers on any
+                                     other kernel run in fp32 unchanged */
     int32_t wino;                 /* nonzero: w_packed holds the packed images of the (Cout, Cin, 3, 4) Winograd F(2, 3) kernel of a 3 x 3,
                                      stride 1, dilation 1, padding 1, groups 1 layer -- U[.][.][kh][0..3] = (g0, (g0 + g1 + g2) / 2,
                                      (g0 - g1 + g2) / 2, g2) of row kh -- and the layer runs csrc/conv_ws3w.h (12 instead of 18

@@ -1,9 +1,10 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r6r
-export AICG_DEV=1
-timeout 600 python -c "
-import aicovergen_amd._lib as L, sys
-L._DEFAULT = L._DEFAULT.replace('hip.so', 'hip_dev.so')
-import pytest
-sys.exit(pytest.main(['tests/test_conv.py', '-q', '-m', 'gpu', '-k', 'winograd_2d and exp15']))" 2>&1 | tail -2
-timeout 600 python tools/kbench_w2d_ab.py 12,15,17 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r6r/kbench_w2d_half_issue.txt
-KB_ONLY=65792 timeout 600 python tools/kbench_w2d_ablate.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r6r/kbench_w2d_half_issue_phases.txt
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r6t
+timeout 900 python -m pytest tests/test_half.py tests/test_conv.py -q -m gpu -x 2>&1 | tail -3
+AICG_DEV=1 timeout 600 python tools/kbench_w2d_ab.py 12,14 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r6t/kbench_w2d_tied_settled.txt
+timeout 600 python tools/kbench_half.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r6t/kbench_half.txt
+timeout 900 python bench.py --precision f16 --no-cpu-baseline > gpurun_out/r6t/bench_c3_f16.json 2> gpurun_out/r6t/bench_c3_f16.err; echo "bench rc=$?"
+python - <<'PY'
+import json
+s = json.loads(open("gpurun_out/r6t/bench_c3_f16.json").read().strip().splitlines()[-1])
+print("C3 f16", round(s["value"], 1), round(s["ms_per_step"], 1), s["config"]["stage_seconds_per_step"], s["config"]["wall_split_seconds_per_step"]["mdx_s"])
+PY
