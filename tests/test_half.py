@@ -183,3 +183,34 @@ def test_hubert_half_against_fp32(monkeypatch):
         outs.append(feats.float().cpu())
     e = rel_rms(outs[1], outs[0])
     assert 1e-6 < e < 1e-2, e
+
+
+@pytest.mark.gpu
+def test_c1_pipeline_half_against_fp32_and_the_reference(monkeypatch):
+    """BASELINE C1 (30 s, full-size networks) through VC.pipeline with HuBERT and the synthesizer in the is_half mode: same f0 (the f0
+    models stay fp32: every coarse bin equal by construction), the int16 waveform within 5e-3 relative rms of the fp32 run and of the
+    REFERENCE's own (fp32, CPU) output of tests/golden/pipeline_c1_30s.npz; reported: the <= 1 LSB rate."""
+    import numpy as np
+    import conftest
+    from synthetic import weights
+    from synthetic.inputs import vocal_like
+    from test_pipeline import build, noise_fn_for
+    conftest._bind("hip")
+    dev = conftest.Dev("hip")
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "pipeline_c1_30s.npz"))
+    seed, x = int(gold["seed"][0]), tuple(int(v) for v in gold["x"])
+    nets = weights.full_model_set(seed)
+    audio = vocal_like(float(gold["seconds"][0]), 16000, seed + 5)
+    monkeypatch.setenv("AICG_HALF", "1")
+    outs = []
+    for half in (False, True):
+        vc, hub, net_g, tgt_sr = build(dev, nets, x)
+        hub, net_g = (hub.half(), net_g.half()) if half else (hub.float(), net_g.float())
+        outs.append(vc.pipeline(hub, net_g, 0, audio, "x.wav", [0, 0, 0], 0, "rmvpe", "", 0.5, 1, 3, tgt_sr, 0, 0.25, "v2", 0.33, 128,
+                                noise_fn=noise_fn_for(nets)))
+    o32, o16, ref = outs[0].astype(np.float64), outs[1].astype(np.float64), gold["audio"].astype(np.float64)
+    e = float(np.sqrt(((o16 - o32) ** 2).sum() / (o32 ** 2).sum()))
+    er = float(np.sqrt(((o16 - ref) ** 2).sum() / (ref ** 2).sum()))
+    print("C1 is_half vs fp32: rel rms %.3e, <= 1 LSB on %.4f; vs the reference's fp32 output: %.3e" % (e, (np.abs(o16 - o32) <= 1).mean(), er))
+    assert 1e-5 < e < 5e-3, e          # measured 5.3e-4 (and 6.8e-4 from the reference: inside SURVEY 8d's fp32 bar of 1e-3)
+    assert er < 5e-3, er

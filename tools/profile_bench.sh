@@ -25,6 +25,8 @@ python tools/kbench_g1w.py -1,0 5 1,3,5 > $OUT/kbench_g1w_policy.txt 2>&1
 python bench.py --conv-shapes $OUT/conv_shapes_c3.json > $OUT/bench_c3_default.json 2> $OUT/bench_c3_default.err
 python bench.py --config C5 --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_c5.json 2>/dev/null
 python bench.py --precision bf16x3 --no-cpu-baseline > $OUT/bench_c3_split.json 2> $OUT/bench_c3_split.err
+python bench.py --precision f16 --no-cpu-baseline > $OUT/bench_c3_f16.json 2> $OUT/bench_c3_f16.err
+python tools/kbench_half.py > $OUT/kbench_half_layers.txt 2>&1
 python bench.py --config C2 --no-cpu-baseline > $OUT/bench_c2.json 2>/dev/null
 python bench.py --config C4 --no-cpu-baseline > $OUT/bench_c4.json 2>/dev/null
 python bench.py --preset fp32 --no-cpu-baseline > $OUT/bench_c3_fp32preset.json 2>/dev/null
