@@ -207,6 +207,7 @@ extern "C" int aicg_conv_forward(const aicg_conv_desc* d, const float* x, const 
             if (d->wino == 9) return run_w2d_ablation(p, st2, 2048);   // no patch pieces at all (wrong results)
             if (d->wino == 10) return run_w2d_ablation(p, st2, 1);     // no DMA at all (wrong results)
             if (d->wino == 14) return run_w2d_pairs_ablation(p, st2, 16384);  // pair fragments, MFMAs through the builtin (untied destinations: accumulator quads through scratch memory)
+            if (d->wino == 15) return run_w2d_pairs_ablation(p, st2, 65536);  // pair fragments, the epilogue one output channel at a time
             if (d->wino == 13) return run_w2d_pairs_ablation(p, st2, 8192);   // pair fragments, place() at the top of the stage that needs it
 #endif
             // 16 (development builds): four waves on pair fragments with 4-channel stages -- two workgroups per CU;

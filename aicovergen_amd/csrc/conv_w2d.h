@@ -207,6 +207,7 @@ template <int NW, int PF, int ABL = 0, int KS = 2>
 __global__ void __launch_bounds__(64 * NW, KS == 1 ? 2 : 1) conv_w2d_kernel(ConvArgs p) {
     constexpr int dbg = ABL;
     constexpr bool OLD_DMA = (ABL & 512) != 0;
+    constexpr bool PK_EPI = (ABL & 65536) == 0;       // the epilogue's additions packed over channel PAIRS (ABL 65536: one channel at a time, for A/B)
     constexpr bool TIED = (ABL & 16384) == 0;         // MFMAs through inline asm with the destination tied to the addend (w2d_mfma_acc); ABL 16384: the builtin, for A/B
     constexpr int BUFS = 3;                          // stage g computes, stage g + 1 has landed (k-step (g, 1) reads ahead into it), stage g + 2 is being filled
     static_assert(PF == 0 || PF == 1 || PF == 2 || PF == 3, "PF 1 / 3: a fragment ring of PF + 1 slots (16 points are a whole number of turns); 0 / 2: groups");
@@ -630,6 +631,70 @@ __global__ void __launch_bounds__(64 * NW, KS == 1 ? 2 : 1) conv_w2d_kernel(Conv
             constexpr bool FULL = decltype(full_tag)::value;
             const int odd = l15 & 1;
             float* ybase = p.y + (long)n * p.y_sn + (long)ho * p.y_sh + (FULL ? (long)odd * y_sh + (wo - 2 * odd) : (long)wo);
+            // what one output channel stores: 2 x 2 outputs of this lane's tile
+            auto store = [&](int m, float y00, float y01, float y10, float y11) __attribute__((always_inline)) {
+                y00 = act_static<ACT>(y00, p.act, p.act_slope);
+                y01 = act_static<ACT>(y01, p.act, p.act_slope);
+                y10 = act_static<ACT>(y10, p.act, p.act_slope);
+                y11 = act_static<ACT>(y11, p.act, p.act_slope);
+                float* dst = ybase + (long)m * y_sc;
+                if constexpr (FULL) {
+                    // what the partner needs of this lane: the even lane's lower row, the odd lane's upper row
+                    const float g0 = quad_xor1(odd ? y00 : y10), g1 = quad_xor1(odd ? y01 : y11);
+                    const float4 v = odd ? make_float4(g0, g1, y10, y11) : make_float4(y00, y01, g0, g1);
+                    if constexpr ((dbg & 128) == 0) *reinterpret_cast<float4*>(dst) = v;
+                    else asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+                } else {
+                    const bool row1 = ho + 1 < p.Ho, col1 = wo + 1 < p.Wo;
+                    if (ho < p.Ho && wo < p.Wo) {
+                        dst[0] = y00;
+                        if (col1) dst[1] = y01;
+                        if (row1) { dst[y_sh] = y10; if (col1) dst[y_sh + 1] = y11; }
+                    }
+                }
+            };
+            if constexpr (PK_EPI) {
+                // A^T M A on channel PAIRS: registers r, r + 1 of an accumulator quad are two consecutive channels of the same point, so the 28
+                // additions of an output channel run as 28 v_pk_add_f32 for two channels on operands that are register pairs as they
+                // stand (vectorised over the outputs of ONE channel, hipcc packed a third of the additions and paid a v_mov per packed operand:
+                // 766 instructions per item, 120 of them moves).  Same additions in the same order per channel: bit-identical.
+                typedef float w2d_f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int rb = 0; rb < 3; ++rb) {
+                    const float4 bq = *reinterpret_cast<const float4*>(brow + rb * 16);
+#pragma unroll
+                    for (int rp = 0; rp < 4; rp += 2) {
+                        w2d_fence();   // one channel pair at a time (hoisted, the store addresses and their temporaries cost accumulator registers)
+                        auto A = [&](int pt) __attribute__((always_inline)) { return w2d_f32x2{acc[pt][rb][rp], acc[pt][rb][rp + 1]}; };
+                        const w2d_f32x2 b2 = rp == 0 ? w2d_f32x2{bq.x, bq.y} : w2d_f32x2{bq.z, bq.w};
+                        // (a - b is v_pk_add_f32 with the negation as an operand modifier: there is no packed subtraction; rows of W = A^T M one
+                        //  at a time, so that at most six pairs are live)
+                        auto sub = [&](w2d_f32x2 a, w2d_f32x2 b) __attribute__((always_inline)) {
+#ifdef AICG_EMULATED
+                            return a - b;
+#else
+                            w2d_f32x2 r;          // (written a + (-b), hipcc folds it back into two scalar v_sub_f32)
+                            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+                            return r;
+#endif
+                        };
+                        auto W0 = [&](int i) __attribute__((always_inline)) { return (A(4 * i) + A(4 * i + 1)) + A(4 * i + 2); };
+                        auto W1 = [&](int i) __attribute__((always_inline)) { return sub(sub(A(4 * i + 1), A(4 * i + 2)), A(4 * i + 3)); };
+                        w2d_f32x2 y00 = W0(0), y01 = W1(0);
+                        const w2d_f32x2 w10 = W0(1), w11 = W1(1);
+                        y00 = y00 + w10; y01 = y01 + w11;
+                        const w2d_f32x2 w20 = W0(2), w21 = W1(2);
+                        y00 = (y00 + w20) + b2; y01 = (y01 + w21) + b2;
+                        w2d_f32x2 y10 = sub(w10, w20), y11 = sub(w11, w21);
+                        const w2d_f32x2 w30 = W0(3), w31 = W1(3);
+                        y10 = sub(y10, w30) + b2; y11 = sub(y11, w31) + b2;
+                        const int m = mu * kW2dM + rb * 16 + 4 * ks + rp;
+                        store(m, y00.x, y01.x, y10.x, y11.x);
+                        store(m + 1, y00.y, y01.y, y10.y, y11.y);
+                    }
+                }
+                return;
+            }
 #pragma unroll
             for (int rb = 0; rb < 3; ++rb) {
                 const float4 bq = *reinterpret_cast<const float4*>(brow + rb * 16);
@@ -644,27 +709,8 @@ __global__ void __launch_bounds__(64 * NW, KS == 1 ? 2 : 1) conv_w2d_kernel(Conv
                         Wc[i][0] = (acc[4 * i][rb][r] + acc[4 * i + 1][rb][r]) + acc[4 * i + 2][rb][r];
                         Wc[i][1] = (acc[4 * i + 1][rb][r] - acc[4 * i + 2][rb][r]) - acc[4 * i + 3][rb][r];
                     }
-                    float y00 = ((Wc[0][0] + Wc[1][0]) + Wc[2][0]) + bm, y01 = ((Wc[0][1] + Wc[1][1]) + Wc[2][1]) + bm;
-                    float y10 = ((Wc[1][0] - Wc[2][0]) - Wc[3][0]) + bm, y11 = ((Wc[1][1] - Wc[2][1]) - Wc[3][1]) + bm;
-                    y00 = act_static<ACT>(y00, p.act, p.act_slope);
-                    y01 = act_static<ACT>(y01, p.act, p.act_slope);
-                    y10 = act_static<ACT>(y10, p.act, p.act_slope);
-                    y11 = act_static<ACT>(y11, p.act, p.act_slope);
-                    float* dst = ybase + (long)m * y_sc;
-                    if constexpr (FULL) {
-                        // what the partner needs of this lane: the even lane's lower row, the odd lane's upper row
-                        const float g0 = quad_xor1(odd ? y00 : y10), g1 = quad_xor1(odd ? y01 : y11);
-                        const float4 v = odd ? make_float4(g0, g1, y10, y11) : make_float4(y00, y01, g0, g1);
-                        if constexpr ((dbg & 128) == 0) *reinterpret_cast<float4*>(dst) = v;
-                        else asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-                    } else {
-                        const bool row1 = ho + 1 < p.Ho, col1 = wo + 1 < p.Wo;
-                        if (ho < p.Ho && wo < p.Wo) {
-                            dst[0] = y00;
-                            if (col1) dst[1] = y01;
-                            if (row1) { dst[y_sh] = y10; if (col1) dst[y_sh + 1] = y11; }
-                        }
-                    }
+                    store(m, ((Wc[0][0] + Wc[1][0]) + Wc[2][0]) + bm, ((Wc[0][1] + Wc[1][1]) + Wc[2][1]) + bm,
+                          ((Wc[1][0] - Wc[2][0]) - Wc[3][0]) + bm, ((Wc[1][1] - Wc[2][1]) - Wc[3][1]) + bm);
                 }
             }
         };

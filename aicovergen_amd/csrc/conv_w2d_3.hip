@@ -5,6 +5,7 @@ namespace aicg {
 int run_w2d_pairs_ablation(ConvArgs& p, hipStream_t st, int bits) {
     switch (bits) {
         case 16384: return launch_conv_w2d<8, 2, 16384>(p, st);    // MFMAs through the builtin (rounds 4-6: accumulator quads through scratch memory)
+        case 65536: return launch_conv_w2d<8, 2, 65536>(p, st);    // the epilogue one output channel at a time (rounds 4-6)
 #ifdef AICG_CONV_ABLATION
         case 262144: return launch_conv_w2d<8, 2, 262144>(p, st);  // the upper wave of a SIMD at issue priority 1
         case 262144 | 256: return launch_conv_w2d<8, 2, 262144 | 256>(p, st);

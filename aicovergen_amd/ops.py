@@ -269,7 +269,7 @@ def _w2d_code():
     """aicg_conv_desc.wino of a layer on the two-dimensional form, and which image it reads ("dword" / "pairs" / "quads")."""
     code = winograd2d_code or ((4 if winograd2d_quads else 12 if winograd2d_pairs else 2) if winograd2d_waves == 8
                                else (5 if winograd2d_quads else 3))
-    return code, ("pairs" if code in (12, 13, 14, 16) else "quads" if code in (4, 5) else "dword")
+    return code, ("pairs" if code in (12, 13, 14, 15, 16) else "quads" if code in (4, 5) else "dword")
 
 
 def winograd2d_image(w, quads=False, pairs=False):
