@@ -1,3 +1,9 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r6w
-timeout 900 python -m pytest tests/test_conv.py tests/test_mdx.py -q -m gpu -x 2>&1 | tail -3
-AICG_DEV=1 timeout 600 python tools/kbench_w2d_ab.py 12,15 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r6w/kbench_w2d_packed_epilogue.txt
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r6y
+for v in 0 1 0 1; do
+AICG_DEV=1 AICG_RB_STREAMS=$v timeout 600 python bench.py --no-cpu-baseline --no-profile-step --steps 3 > gpurun_out/r6y/b$v.json 2>/dev/null
+python - $v <<'PY'
+import json,sys
+s=json.loads(open("gpurun_out/r6y/b%s.json"%sys.argv[1]).read().strip().splitlines()[-1])
+print("RB_STREAMS", sys.argv[1], round(s["ms_per_step"],1), s["config"]["stage_seconds_per_step"])
+PY
+done
