@@ -416,11 +416,14 @@ def main():
         }
         if prof is not None:
             conv = prof.summary()
-            traffic = None if split_mode else pmc_traffic_per_launch()   # the committed PMC passes are of the default (fp32) command
+            traffic = None if (split_mode or half_mode) else pmc_traffic_per_launch()   # the committed PMC passes are of the default (fp32) command
             res["roofline"] = {
                 # `achieved` is what SURVEY 8(d) defines: every layer's DIRECT-form flops over the family's kernel time.  The Winograd
                 # layers execute 4/9 (two-dimensional form) or 2/3 (row form) of those multiply-adds, so `achieved` is an effective
                 # rate and may exceed the peak; the fraction of the matrix pipe's roofline is `frac` = executed / peak.
+                **({"mixed_precision_note": "--precision f16: the marked layers of the RVC half execute on the fp16 matrix pipe (a quarter of the MFMA "
+                    "cycles per multiply-add); `frac` prices ALL executed flops against the fp32 peak and is NOT a pipe utilisation on this line -- "
+                    "`dominant_kernel` (conv_w2d, fp32 either way) is"} if half_mode else {}),
                 "bound": "mfma", "achieved": conv["tflops"], "peak": MFMA_PEAK, "unit": "TFLOP/s",
                 "frac": conv["tflops_executed"] / MFMA_PEAK,
                 "frac_algorithmic": conv["tflops"] / MFMA_PEAK,
