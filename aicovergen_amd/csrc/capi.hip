@@ -51,7 +51,7 @@ void note_launch(const char* what) { g_last_launch = what; }
 
 extern "C" const char* aicg_last_error(void) { return aicg::g_err; }
 extern "C" const char* aicg_last_launch(void) { return aicg::g_last_launch; }
-extern "C" int aicg_abi_version(void) { return 4; }  // 2: aicg_conv_desc gained shuffle / res_mul; 3: gemm_tile, aicg_last_launch; 4: aicg_rownorm_act_ld
+extern "C" int aicg_abi_version(void) { return 5; }  // 2: aicg_conv_desc gained shuffle / res_mul; 3: gemm_tile, aicg_last_launch; 4: aicg_rownorm_act_ld; 5: aicg_conv_desc.split == 2 means fp16 operands (before: any nonzero value = the bf16 split)
 
 // Diagnostic: issue-bound fp32 MFMA loop (no memory traffic) to calibrate the attainable v_mfma_f32_32x32x2_f32 rate
 // of the device the benchmarks run on (clock under load is power-dependent).  Returns nothing useful in `out` beyond

@@ -41,7 +41,7 @@ def test_hip_library_exports_every_declared_symbol(hip_lib):
 
 def test_abi_version_and_error_reporting_without_gpu(hip_lib):
     hip_lib.aicg_abi_version.restype = ctypes.c_int
-    assert hip_lib.aicg_abi_version() == 4
+    assert hip_lib.aicg_abi_version() == 5
     hip_lib.aicg_last_error.restype = ctypes.c_char_p
     # argument validation happens before any HIP call: null pointers -> AICG_E_ARG (-2) and a message, no device needed
     hip_lib.aicg_complex_abs.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int64, ctypes.c_void_p]
