@@ -552,13 +552,12 @@ __global__ void __launch_bounds__(64 * NW, KS == 1 ? 2 : 1) conv_w2d_kernel(Conv
         if (!first_stage && (dbg & 32) == 0) lds_barrier();
         first_stage = false;
         stamp(std::integral_constant<int, 0>{});
-        // (an item's first stage issues its DMA BEHIND the first k-step: hipcc guards the registers the epilogue's stores read with a
-        // vmcnt(0) in front of the first MFMA that overwrites them, which must meet those stores only, not DMA pieces issued a moment ago)
-        // The stage's DMA goes out as one burst per wave at the top of the stage.  (Measured alternatives, DESIGN 2.9: one piece at a time
-        // from inside the MFMA stream -- slower; the two waves of a SIMD bursting in turns -- 6 % slower on level 0, 1 % faster on the
-        // deep levels; the first stage bursting right behind open_kstep -- 1-2 % slower.)  An item's FIRST stage bursts behind
-        // its first k-step: hipcc guards the registers the epilogue's stores read with a vmcnt(0) in front of the first MFMA that
-        // overwrites them, which must meet those stores only, not DMA pieces issued a moment ago.
+        // The stage's DMA goes out as one burst per wave at the top of the stage.  (Measured alternatives, DESIGN 2.2 / NOTES R6.2b: one piece
+        // at a time from inside the MFMA stream -- 3-4 % slower; the two waves of a SIMD bursting in turns, the upper wave bursting for
+        // both, the burst behind the first k-step -- slower or level.)  An item's FIRST stage bursts behind its first k-step: with the
+        // builtin MFMAs hipcc guarded the registers the epilogue's stores read with a vmcnt(0) in front of the first MFMA that overwrote
+        // them, which had to meet those stores only, not DMA pieces issued a moment ago; on the tied form the guard is gone and the burst
+        // at the top of the first stage measures level (profiles/r06_kbench_w2d_first_stage_burst_at_top.txt) -- left where it is.
         if constexpr (!FIRST) issue(b_fill);
         lane_offsets();
         if constexpr (FIRST) open_kstep(b_cur);
