@@ -18,11 +18,12 @@ def regs(text):
     return out
 
 
-def scan(text):
+def scan(text, name_filter="conv_w2d_kernel", result_ws=11):
+    """result_ws: wait states behind an MFMA before its result may be read (8-pass: 11; 16-pass: 19)"""
     res = {}
     for blk in re.split(r"\n(?=_Z\w+:)", text):
         name = blk.split(":", 1)[0]
-        if "conv_w2d_kernel" not in name or "s_endpgm" not in blk:
+        if name_filter not in name or "s_endpgm" not in blk:
             continue
         lines = blk[:blk.index("s_endpgm")].split("\n")
         mfma_w, valu_w = {}, {}          # register -> wait states since it was written by an MFMA / a VALU instruction
@@ -49,7 +50,7 @@ def scan(text):
                 is_store = re.match(r"\s*(global_store|scratch_store|ds_write|buffer_store)", l)
                 srcs = parts if is_store else parts[1:]
                 for r in regs(",".join(srcs)):
-                    if mfma_w.get(r, 99) < 11:
+                    if mfma_w.get(r, 99) < result_ws:
                         v1 += 1
                         ex.append(("mfma->read", l.strip(), r, mfma_w[r]))
                 if VALU.match(l) and parts:
@@ -69,6 +70,11 @@ def scan(text):
 
 
 if __name__ == "__main__":
-    src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(isa_check.CSRC, "conv_w2d_1.hip")
-    for k, (v1, v2, ex) in scan(isa_check.compile_asm(src)).items():
-        print(k[:70], "| MFMA result read early:", v1, "| VALU result read early by an MFMA:", v2, ex)
+    if len(sys.argv) > 1:
+        jobs = [(sys.argv[1], "_kernel", 19)]
+    else:   # conv_w2d (asm MFMAs) and the fp16-operand kernels (asm v_cvt_pk_f16_f32 in front of builtin 16-pass MFMAs)
+        jobs = [(os.path.join(isa_check.CSRC, "conv_w2d_1.hip"), "conv_w2d_kernel", 11), (os.path.join(isa_check.CSRC, "conv_g1_2.hip"), "conv_g1_kernel", 0),
+                (os.path.join(isa_check.CSRC, "conv_g1w_4.hip"), "conv_g1w_kernel", 0)]   # (builtin MFMAs: hipcc guards their results itself; 0 = not scanned)
+    for src, flt, ws in jobs:
+        for k, (v1, v2, ex) in scan(isa_check.compile_asm(src), flt, ws).items():
+            print(k[:70], "| MFMA result read early:", v1, "| VALU result read early by an MFMA:", v2, ex)
